@@ -1,0 +1,278 @@
+/*
+ * kanter_core_amd.h -- C ABI of the MI355X (gfx950) per-pixel evaluation backend for
+ * kanter_core / vismut_core 0.10.0 graphs.
+ *
+ * This is the drop-in boundary: plain pointers, sizes and opaque handles, no C++ or torch types.
+ * The reference (pure Rust, no FFI of its own) would bind these from an `extern "C"` block and
+ * call them from the bodies behind its operator boundary, `process_node`
+ * (src/node/node_type.rs:213-248) and the per-node `process` functions it dispatches to
+ * (src/node/node_type.rs:107-122).  Each entry point cites the reference interface it replaces;
+ * paths are relative to the reference checkout.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Data model (replaces src/slot_image.rs:12-19 and src/transient_buffer.rs):
+ *   kc_plane  one channel: row-major f32, `pitch` bytes per row (pitch >= 4*width, 256-byte
+ *             aligned for planes this library allocates) living in HBM -- or a broadcast
+ *             constant / a not-yet-materialised pointwise chain (see kc_plane_materialize).
+ *             Planes are immutable once published and shared by reference count exactly where
+ *             the reference clones an Arc<TransientBufferContainer>.
+ *   kc_image  SlotImage: Gray = 1 plane, Rgba = 4 planes (R, G, B, A).
+ *
+ * All functions return a kc_status (0 = ok).  1..19 mirror TexProError (src/error.rs:5-27);
+ * >= 100 are backend errors.  Every entry point is thread-safe; work is enqueued in order on
+ * one HIP stream per process (kc_set_stream) and is complete after kc_sync() or any call that
+ * returns host data.
+ */
+#ifndef KANTER_CORE_AMD_H
+#define KANTER_CORE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KC_API __attribute__((visibility("default")))
+
+/* ---- status codes: TexProError, src/error.rs:5-27 --------------------------------------- */
+typedef enum kc_status {
+    KC_OK = 0,
+    KC_ERR_GENERIC = 1,
+    KC_ERR_CANCELED = 2,
+    KC_ERR_IMAGE = 3,
+    KC_ERR_INVALID_BUFFER_COUNT = 4,
+    KC_ERR_INVALID_NODE_ID = 5,
+    KC_ERR_INVALID_NODE_TYPE = 6,
+    KC_ERR_INVALID_SLOT_ID = 7,
+    KC_ERR_INVALID_SLOT_TYPE = 8,
+    KC_ERR_INVALID_EDGE = 9,
+    KC_ERR_NO_SLOT_DATA = 10,
+    KC_ERR_SLOT_OCCUPIED = 11,
+    KC_ERR_SLOT_NOT_OCCUPIED = 12,
+    KC_ERR_UNABLE_TO_LOCK = 13,
+    KC_ERR_NODE_PROCESSING = 14,
+    KC_ERR_POISON = 15,
+    KC_ERR_TRY_LOCK = 16,
+    KC_ERR_NODE_DIRTY = 17,
+    KC_ERR_IO = 18,
+    KC_ERR_INVALID_NAME = 19,
+    /* backend */
+    KC_ERR_HIP = 100,          /* a HIP runtime call failed; kc_last_error() has the text */
+    KC_ERR_NO_DEVICE = 101,    /* no gfx950 device / kc_init not called: there is NO CPU fallback */
+    KC_ERR_INVALID_ARG = 102,
+    KC_ERR_OUT_OF_MEMORY = 103,
+    KC_ERR_UNSUPPORTED = 104
+} kc_status;
+
+/* MixType, src/node/mix.rs:20-27 */
+typedef enum kc_mix_type { KC_MIX_ADD = 0, KC_MIX_SUBTRACT = 1, KC_MIX_MULTIPLY = 2, KC_MIX_DIVIDE = 3, KC_MIX_POW = 4 } kc_mix_type;
+/* ResizeFilter, src/node/mod.rs:62-69 (default Triangle, :71-75) */
+typedef enum kc_resize_filter { KC_FILTER_NEAREST = 0, KC_FILTER_TRIANGLE = 1, KC_FILTER_CATMULLROM = 2, KC_FILTER_GAUSSIAN = 3, KC_FILTER_LANCZOS3 = 4 } kc_resize_filter;
+/* ResizePolicy, src/node/mod.rs:33-41 (default MostPixels, :43-47) */
+typedef enum kc_resize_policy { KC_POLICY_MOST_PIXELS = 0, KC_POLICY_LEAST_PIXELS = 1, KC_POLICY_LARGEST_AXES = 2, KC_POLICY_SMALLEST_AXES = 3, KC_POLICY_SPECIFIC_SLOT = 4, KC_POLICY_SPECIFIC_SIZE = 5 } kc_resize_policy;
+/* NodeType, src/node/node_type.rs:14-28 */
+typedef enum kc_node_type {
+    KC_NODE_INPUT_GRAY = 0, KC_NODE_INPUT_RGBA = 1, KC_NODE_OUTPUT_GRAY = 2, KC_NODE_OUTPUT_RGBA = 3,
+    KC_NODE_GRAPH = 4, KC_NODE_IMAGE = 5, KC_NODE_EMBED = 6, KC_NODE_WRITE = 7, KC_NODE_VALUE = 8,
+    KC_NODE_MIX = 9, KC_NODE_HEIGHT_TO_NORMAL = 10, KC_NODE_SEPARATE_RGBA = 11, KC_NODE_COMBINE_RGBA = 12
+} kc_node_type;
+/* NodeState, src/live_graph.rs:22-37 */
+typedef enum kc_node_state { KC_STATE_CLEAN = 0, KC_STATE_DIRTY = 1, KC_STATE_REQUESTED = 2, KC_STATE_PRIORITISED = 3, KC_STATE_PROCESSING = 4, KC_STATE_PROCESSING_DIRTY = 5 } kc_node_state;
+/* Side, src/node/mod.rs:101-105 */
+typedef enum kc_side { KC_SIDE_INPUT = 0, KC_SIDE_OUTPUT = 1 } kc_side;
+
+typedef struct kc_plane kc_plane;
+typedef struct kc_image kc_image;
+typedef struct kc_node_graph kc_node_graph;
+typedef struct kc_live_graph kc_live_graph;
+typedef struct kc_tex_pro kc_tex_pro;
+
+/* Size, src/slot_data.rs:4-30 */
+typedef struct kc_size { uint32_t width, height; } kc_size;
+/* Edge, src/edge.rs:8-14 */
+typedef struct kc_edge { uint32_t output_id, input_id, output_slot, input_slot; } kc_edge;
+
+/* Node, src/node/mod.rs:113-123 (priority / cancel are host scheduling state, not carried). */
+typedef struct kc_node_desc {
+    uint32_t node_id;          /* NodeId */
+    int32_t node_type;         /* kc_node_type */
+    int32_t mix_type;          /* kc_mix_type, for KC_NODE_MIX */
+    float value;               /* for KC_NODE_VALUE */
+    uint32_t embed_id;         /* EmbeddedSlotDataId, for KC_NODE_EMBED */
+    const char *text;          /* Input/Output name, Image/Write path; may be NULL */
+    const kc_node_graph *graph;/* nested graph for KC_NODE_GRAPH (copied) */
+    int32_t resize_policy;     /* kc_resize_policy */
+    uint32_t policy_slot;      /* SpecificSlot(SlotId) */
+    kc_size policy_size;       /* SpecificSize(Size) */
+    int32_t resize_filter;     /* kc_resize_filter */
+} kc_node_desc;
+
+/* ========================================================================================== *
+ * Device / context
+ * ========================================================================================== */
+/* Binds the process to one gfx950 device (one process per GPU).  Fails with KC_ERR_NO_DEVICE
+ * when no GPU is present -- the library never computes on the CPU. */
+KC_API int kc_init(int device_ordinal);
+KC_API int kc_shutdown(void);
+KC_API int kc_is_initialized(void);
+/* Enqueue all work on the caller's hipStream_t (e.g. torch's current stream); NULL restores the
+ * library's own stream.  Replaces the reference's thread-per-node scheduling, src/engine.rs:288. */
+KC_API int kc_set_stream(void *hip_stream);
+KC_API void *kc_get_stream(void);
+KC_API int kc_sync(void);
+KC_API const char *kc_last_error(void);
+KC_API const char *kc_status_string(int status);
+/* 1 (default): pointwise Mix chains whose intermediates are never observed are evaluated by one
+ * fused kernel; 0: every node materialises its planes.  Results are bit-identical either way. */
+KC_API int kc_set_fusion(int enabled);
+KC_API int kc_get_fusion(void);
+/* Pool statistics: bytes currently handed out, bytes cached for reuse, kernels launched. */
+KC_API int kc_stats(uint64_t *bytes_in_use, uint64_t *bytes_cached, uint64_t *kernel_launches);
+KC_API int kc_pool_trim(void);
+
+/* ========================================================================================== *
+ * Planes -- replaces Buffer / TransientBufferContainer (src/slot_image.rs:12,
+ * src/transient_buffer.rs:188-247); HBM replaces the RAM/disk tiering.
+ * ========================================================================================== */
+KC_API int kc_plane_alloc(uint32_t width, uint32_t height, kc_plane **out);
+/* Broadcast constant: what `vec![v; n]` (src/slot_image.rs:28-64) and the 1x1 Value plane
+ * (src/node/mod.rs:240-244) hold, kept as a scalar until somebody needs the bytes. */
+KC_API int kc_plane_const(uint32_t width, uint32_t height, float value, kc_plane **out);
+/* Wrap caller-owned device memory (e.g. a torch tensor); not freed by the library. */
+KC_API int kc_plane_wrap(void *device_ptr, uint32_t width, uint32_t height, size_t pitch_bytes, kc_plane **out);
+KC_API int kc_plane_retain(kc_plane *p);
+KC_API int kc_plane_release(kc_plane *p);
+KC_API int kc_plane_size(const kc_plane *p, uint32_t *width, uint32_t *height);
+KC_API int kc_plane_is_const(const kc_plane *p, int *is_const, float *value);
+/* Forces the plane into HBM (runs any pending fused chain, fills constants). */
+KC_API int kc_plane_materialize(kc_plane *p);
+/* Materialises, then returns the device pointer and pitch (valid while the plane is retained). */
+KC_API int kc_plane_device_ptr(kc_plane *p, void **device_ptr, size_t *pitch_bytes);
+KC_API int kc_plane_upload_f32(kc_plane *p, const float *host, size_t host_pitch_bytes);
+KC_API int kc_plane_download_f32(kc_plane *p, float *host, size_t host_pitch_bytes);
+
+/* ========================================================================================== *
+ * Images -- SlotImage, src/slot_image.rs:15-264
+ * ========================================================================================== */
+KC_API int kc_image_gray(kc_plane *p, kc_image **out);                 /* SlotImage::Gray */
+KC_API int kc_image_rgba(kc_plane *const planes[4], kc_image **out);   /* SlotImage::Rgba */
+KC_API int kc_image_retain(kc_image *img);
+KC_API int kc_image_release(kc_image *img);
+KC_API int kc_image_is_rgba(const kc_image *img, int *is_rgba);        /* slot_image.rs:123-139 */
+KC_API int kc_image_size(const kc_image *img, kc_size *size);          /* slot_image.rs:116-121 */
+KC_API int kc_image_plane(const kc_image *img, int channel, kc_plane **out); /* +1 reference */
+KC_API int kc_image_from_value(kc_size size, float value, int rgba, kc_image **out); /* :28-64 */
+KC_API int kc_image_as_type(const kc_image *img, int rgba, kc_image **out);          /* :212-256 */
+KC_API int kc_image_materialize(kc_image *img);
+/* deconstruct_image + read_slot_image, src/shared.rs:16-56,218-261: interleaved u8 with 1..4
+ * channels -> RGBA planes (/255., missing R,G,B = 0, A = 1). */
+KC_API int kc_image_from_u8(const uint8_t *host, uint32_t width, uint32_t height, int channels, kc_image **out);
+/* to_u8 / to_u8_srgb, src/slot_image.rs:141-207: -> interleaved RGBA8 (width*height*4 bytes). */
+KC_API int kc_image_to_u8(kc_image *img, int srgb, uint8_t *host_rgba8);
+KC_API int kc_image_from_f32(const float *const host_planes[], int n_planes, uint32_t width, uint32_t height, kc_image **out);
+KC_API int kc_image_to_f32(kc_image *img, float *const host_planes[], int n_planes);
+/* read_slot_image, src/shared.rs:218-261 (PNG only; decode on host, planes built on device). */
+KC_API int kc_image_read_png(const char *path, kc_image **out);
+KC_API int kc_image_write_png(kc_image *img, const char *path);        /* src/node/write.rs:5-21 */
+
+/* ========================================================================================== *
+ * Per-node operators -- the functions behind process_node_internal, src/node/node_type.rs:98-138.
+ * Inputs arrive already resized and keyed by input slot (NULL = slot not connected), as after
+ * resize_buffers + assign_slot_ids (node_type.rs:229-237,250-267).
+ * ========================================================================================== */
+/* calculate_size, src/shared.rs:61-139.  sizes[] in edge insertion order; slot_index = index of
+ * the input SpecificSlot resolves to, or -1. */
+KC_API int kc_calculate_size(int policy, const kc_size *sizes, int n, int slot_index, kc_size specific, kc_size *out);
+/* image::imageops::resize per plane, call sites src/shared.rs:159-199. */
+KC_API int kc_resize_image(kc_image *src, kc_size size, int filter, kc_image **out);
+/* resize_buffers, src/shared.rs:141-216: images[] in edge insertion order, edges[] sorted by
+ * input_slot (node_type.rs:230-231); keys[i] = (output node id, output slot id) of images[i]. */
+KC_API int kc_resize_buffers(kc_image *const images[], const kc_edge keys[], int n, const kc_edge *edges_sorted,
+                             int n_edges, int policy, uint32_t policy_slot, kc_size policy_size, int filter,
+                             kc_image *out[]);
+/* mix::process, src/node/mix.rs:51-134.  *out = NULL with KC_OK when the reference returns an
+ * empty Vec (mixed Gray/Rgba after type matching, :126). */
+KC_API int kc_mix_process(kc_image *left, kc_image *right, int mix_type, kc_image **out);
+/* separate_rgba::process, src/node/separate_rgba.rs:38-69 */
+KC_API int kc_separate_rgba_process(kc_image *input, kc_image *out[4]);
+/* combine_rgba::process, src/node/combine_rgba.rs:14-97; first = slot_datas.get(0) (size source). */
+KC_API int kc_combine_rgba_process(kc_image *const inputs[4], kc_image **out);
+/* value::process, src/node/value.rs:14-26 */
+KC_API int kc_value_process(float value, kc_image **out);
+/* height_to_normal::process, src/node/height_to_normal.rs:16-77; *out = NULL when the reference
+ * returns an empty Vec (no input / RGBA input). */
+KC_API int kc_height_to_normal_process(kc_image *input, kc_image **out);
+
+/* ========================================================================================== *
+ * NodeGraph -- src/node_graph.rs:16-590
+ * ========================================================================================== */
+KC_API int kc_node_graph_new(kc_node_graph **out);                                  /* :25-31 */
+KC_API int kc_node_graph_clone(const kc_node_graph *g, kc_node_graph **out);
+KC_API int kc_node_graph_free(kc_node_graph *g);
+KC_API int kc_node_graph_from_path(const char *path, kc_node_graph **out);          /* :33-46 */
+KC_API int kc_node_graph_from_json(const char *json, kc_node_graph **out);          /* :104-107 */
+KC_API int kc_node_graph_export_json(const kc_node_graph *g, const char *path);     /* :98-102 */
+/* Serialises into buf (NUL-terminated); *needed = bytes required including the NUL. */
+KC_API int kc_node_graph_to_json(const kc_node_graph *g, char *buf, size_t cap, size_t *needed);
+KC_API int kc_node_graph_add_node(kc_node_graph *g, const kc_node_desc *node, uint32_t *node_id);       /* :315-320 */
+KC_API int kc_node_graph_add_node_with_id(kc_node_graph *g, const kc_node_desc *node);                  /* :322-331 */
+KC_API int kc_node_graph_connect(kc_node_graph *g, uint32_t output_node, uint32_t input_node, uint32_t output_slot, uint32_t input_slot); /* :416-446 */
+KC_API int kc_node_graph_try_connect(kc_node_graph *g, uint32_t output_node, uint32_t input_node, uint32_t output_slot, uint32_t input_slot); /* :396-413 */
+KC_API int kc_node_graph_remove_node(kc_node_graph *g, uint32_t node_id);                              /* :473-481 */
+KC_API int kc_node_graph_remove_edge(kc_node_graph *g, kc_edge edge);                                  /* :462-471 */
+KC_API int kc_node_graph_disconnect_slot(kc_node_graph *g, uint32_t node_id, int side, uint32_t slot_id); /* :496-515 */
+KC_API int kc_node_graph_node_count(const kc_node_graph *g, uint32_t *count);
+KC_API int kc_node_graph_node_ids(const kc_node_graph *g, uint32_t *ids, uint32_t cap, uint32_t *count); /* :125-127 */
+KC_API int kc_node_graph_edges(const kc_node_graph *g, kc_edge *edges, uint32_t cap, uint32_t *count);
+KC_API int kc_node_graph_input_slot_id_with_name(const kc_node_graph *g, const char *name, uint32_t *slot_id);  /* :271-276 */
+KC_API int kc_node_graph_output_slot_id_with_name(const kc_node_graph *g, const char *name, uint32_t *slot_id); /* :278-283 */
+KC_API int kc_node_graph_set_mix_type(kc_node_graph *g, uint32_t node_id, int mix_type);               /* :48-63 */
+
+/* ========================================================================================== *
+ * TextureProcessor / LiveGraph -- src/texture_processor.rs:18-115, src/live_graph.rs:63-645.
+ * Evaluation is synchronous and stream-ordered: await_clean runs every dirty ancestor in
+ * topological order on the calling thread (replaces engine::process_loop, src/engine.rs:25-312).
+ * ========================================================================================== */
+KC_API int kc_tex_pro_new(uint64_t memory_threshold, kc_tex_pro **out);              /* texture_processor.rs:34-56 */
+KC_API int kc_tex_pro_free(kc_tex_pro *tp);
+KC_API int kc_tex_pro_new_live_graph(kc_tex_pro *tp, kc_live_graph **out);           /* :58-64 */
+KC_API int kc_live_graph_free(kc_live_graph *lg);
+KC_API int kc_live_graph_set_flags(kc_live_graph *lg, int auto_update, int use_cache); /* live_graph.rs:71-72 */
+KC_API int kc_live_graph_get_flags(const kc_live_graph *lg, int *auto_update, int *use_cache);
+KC_API int kc_live_graph_set_node_graph(kc_live_graph *lg, const kc_node_graph *g);  /* :605-609 */
+KC_API int kc_live_graph_node_graph(const kc_live_graph *lg, kc_node_graph **out_clone);
+KC_API int kc_live_graph_add_node(kc_live_graph *lg, const kc_node_desc *node, uint32_t *node_id);      /* :426-433 */
+KC_API int kc_live_graph_add_node_with_id(kc_live_graph *lg, const kc_node_desc *node);                 /* :435-444 */
+KC_API int kc_live_graph_remove_node(kc_live_graph *lg, uint32_t node_id);                              /* :452-475 */
+KC_API int kc_live_graph_connect(kc_live_graph *lg, uint32_t output_node, uint32_t input_node, uint32_t output_slot, uint32_t input_slot); /* :488-511 */
+KC_API int kc_live_graph_remove_edge(kc_live_graph *lg, kc_edge edge);                                  /* :551-566 */
+KC_API int kc_live_graph_disconnect_slot(kc_live_graph *lg, uint32_t node_id, int side, uint32_t slot_id); /* :568-594 */
+KC_API int kc_live_graph_set_mix_type(kc_live_graph *lg, uint32_t node_id, int mix_type);               /* node_mut, :369-374 */
+KC_API int kc_live_graph_set_resize(kc_live_graph *lg, uint32_t node_id, int policy, uint32_t policy_slot, kc_size policy_size, int filter);
+KC_API int kc_live_graph_node_state(const kc_live_graph *lg, uint32_t node_id, int *state);             /* :244-250 */
+KC_API int kc_live_graph_request(kc_live_graph *lg, uint32_t node_id);                                  /* :219-227 */
+KC_API int kc_live_graph_prioritise(kc_live_graph *lg, uint32_t node_id);                               /* :229-237 */
+/* await_clean_read / await_clean_write, :164-195: returns once node_id is Clean. */
+KC_API int kc_live_graph_await_clean(kc_live_graph *lg, uint32_t node_id);
+/* One scheduler pass: processes every Requested / Prioritised node (all non-clean nodes when
+ * auto_update), src/engine.rs:128-183. */
+KC_API int kc_live_graph_update(kc_live_graph *lg);
+KC_API int kc_live_graph_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image **out);   /* :415-420, +1 ref */
+KC_API int kc_live_graph_slot_data_size(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_size *size); /* :406-408 */
+KC_API int kc_live_graph_slot_in_memory(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, int *in_memory); /* :410-412 */
+KC_API int kc_live_graph_node_slot_ids(kc_live_graph *lg, uint32_t node_id, uint32_t *slot_ids, uint32_t cap, uint32_t *count); /* node_slot_datas, :389-404 */
+KC_API int kc_live_graph_buffer_rgba(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, int srgb, uint8_t *host_rgba8); /* :93-95 */
+KC_API int kc_live_graph_embed_slot_data_with_id(kc_live_graph *lg, kc_image *image, uint32_t slot_id, uint32_t embed_id); /* :324-341 */
+KC_API int kc_live_graph_add_input_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image *image);     /* :347-350 */
+KC_API int kc_live_graph_changed_consume(kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count);               /* :156-160 */
+KC_API int kc_live_graph_output_ids(const kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count);              /* :621-623 */
+KC_API int kc_live_graph_node_ids(const kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count);                /* :629-631 */
+KC_API int kc_live_graph_edges(const kc_live_graph *lg, kc_edge *edges, uint32_t cap, uint32_t *count);                  /* :633-635 */
+/* Base directory that relative Image / Write paths resolve against (the reference resolves them
+ * against the process's working directory). */
+KC_API int kc_live_graph_set_base_dir(kc_live_graph *lg, const char *dir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KANTER_CORE_AMD_H */

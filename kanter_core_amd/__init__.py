@@ -1,0 +1,13 @@
+"""kanter_core_amd -- MI355X (gfx950) per-pixel evaluation backend for kanter_core / vismut_core
+graphs.  The product is libkanter_core_amd.so (C ABI: include/kanter_core_amd.h, hand-written HIP
+kernels in csrc/kernels.hip); this package mirrors the reference's host API on top of it.
+Build the library with `python -m kanter_core_amd.build`; importing `api` symbols that touch the
+device fails loudly when it is missing -- there is no CPU fallback.
+"""
+from .api import (Edge, EmbeddedSlotDataId, LiveGraph, MixType, Node, NodeGraph, NodeId, NodeState, NodeType,  # noqa: F401
+                  ResizeFilter, ResizePolicy, Side, Size, SlotData, SlotId, SlotImage, TexProError,
+                  TextureProcessor, calculate_size, combine_rgba_process, get_stream, height_to_normal_process,
+                  init, is_initialized, mix_process, resize_image, separate_rgba_process, set_fusion, set_stream,
+                  shutdown, stats, sync, value_process)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

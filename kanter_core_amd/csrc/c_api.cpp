@@ -1,0 +1,942 @@
+// extern "C" surface declared in include/kanter_core_amd.h.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "kc_runtime.hpp"
+
+namespace kc {
+const std::string &last_error();
+}
+using namespace kc;
+
+#define KC_ARG(cond)                                         \
+    do {                                                     \
+        if (!(cond)) {                                       \
+            set_error("invalid argument: " #cond);           \
+            return KC_ERR_INVALID_ARG;                       \
+        }                                                    \
+    } while (0)
+
+typedef std::lock_guard<std::recursive_mutex> Lock;
+
+extern "C" {
+
+// ---------------------------------------------------------------- context
+int kc_init(int device_ordinal)
+{
+    Context &c = ctx();
+    Lock lk(c.mu);
+    if (c.inited) {
+        if (c.device == device_ordinal) return KC_OK;
+        set_error("kc_init: already bound to another device (one process per GPU)");
+        return KC_ERR_INVALID_ARG;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available: kanter_core_amd has no CPU fallback");
+        return KC_ERR_NO_DEVICE;
+    }
+    KC_ARG(device_ordinal >= 0 && device_ordinal < count);
+    KC_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    KC_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return KC_ERR_NO_DEVICE;
+    }
+    KC_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.stream = c.own_stream;
+    c.device = device_ordinal;
+    if (const char *mb = std::getenv("KC_MAX_BLOCKS")) {
+        int v = std::atoi(mb);
+        if (v >= 1) c.max_blocks = v;
+    }
+    if (const char *tp = std::getenv("KC_RESIZE_TWO_PASS")) c.resize_two_pass = std::atoi(tp) != 0;
+    c.inited = true;
+    return KC_OK;
+}
+
+int kc_shutdown(void)
+{
+    Context &c = ctx();
+    Lock lk(c.mu);
+    if (!c.inited) return KC_OK;
+    (void)hipStreamSynchronize(c.stream);
+    pool_trim();
+    for (auto &kv : c.taps) (void)hipFree(kv.second.dev_block);
+    c.taps.clear();
+    if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+    c.own_stream = c.stream = nullptr;
+    c.inited = false;
+    c.device = -1;
+    return KC_OK;
+}
+
+int kc_is_initialized(void) { return ctx().inited ? 1 : 0; }
+
+int kc_set_stream(void *hip_stream)
+{
+    KC_TRY(need_init());
+    Context &c = ctx();
+    Lock lk(c.mu);
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : c.own_stream;
+    if (next != c.stream) {
+        // pool blocks are recycled in stream order: drain the old stream before switching
+        KC_HIP(hipStreamSynchronize(c.stream));
+        c.stream = next;
+    }
+    return KC_OK;
+}
+
+void *kc_get_stream(void) { return (void *)ctx().stream; }
+
+int kc_sync(void)
+{
+    KC_TRY(need_init());
+    KC_HIP(hipStreamSynchronize(ctx().stream));
+    return KC_OK;
+}
+
+const char *kc_last_error(void) { return last_error().c_str(); }
+
+const char *kc_status_string(int s)
+{
+    switch (s) {
+    case KC_OK: return "ok";
+    case KC_ERR_GENERIC: return "Something went wrong";
+    case KC_ERR_CANCELED: return "Node processing was canceled";
+    case KC_ERR_IMAGE: return "Image error";
+    case KC_ERR_INVALID_BUFFER_COUNT: return "Invalid number of channels";
+    case KC_ERR_INVALID_NODE_ID: return "Invalid `NodeId`";
+    case KC_ERR_INVALID_NODE_TYPE: return "Invalid `NodeType`";
+    case KC_ERR_INVALID_SLOT_ID: return "Invalid `SlotId`";
+    case KC_ERR_INVALID_SLOT_TYPE: return "Invalid `SlotType`";
+    case KC_ERR_INVALID_EDGE: return "Invalid `Edge`";
+    case KC_ERR_NO_SLOT_DATA: return "Could not find a `SlotData`";
+    case KC_ERR_SLOT_OCCUPIED: return "`SlotId` is already in use";
+    case KC_ERR_SLOT_NOT_OCCUPIED: return "`SlotId` is not in use";
+    case KC_ERR_UNABLE_TO_LOCK: return "Unable to get a lock";
+    case KC_ERR_NODE_PROCESSING: return "Error during node processing";
+    case KC_ERR_POISON: return "Error with poisoned lock";
+    case KC_ERR_TRY_LOCK: return "Error when trying to lock";
+    case KC_ERR_NODE_DIRTY: return "The node is not up to date";
+    case KC_ERR_IO: return "I/O error";
+    case KC_ERR_INVALID_NAME: return "Invalid name, can only contain lowercase letters, numbers and underscores";
+    case KC_ERR_HIP: return "HIP runtime error";
+    case KC_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
+    case KC_ERR_INVALID_ARG: return "invalid argument";
+    case KC_ERR_OUT_OF_MEMORY: return "out of HBM";
+    case KC_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown status";
+}
+
+int kc_set_fusion(int enabled)
+{
+    ctx().fusion = enabled != 0;
+    return KC_OK;
+}
+
+int kc_get_fusion(void) { return ctx().fusion ? 1 : 0; }
+
+int kc_stats(uint64_t *in_use, uint64_t *cached, uint64_t *launches)
+{
+    Context &c = ctx();
+    Lock lk(c.mu);
+    if (in_use) *in_use = c.bytes_in_use;
+    if (cached) *cached = c.bytes_cached;
+    if (launches) *launches = c.launches;
+    return KC_OK;
+}
+
+int kc_pool_trim(void)
+{
+    KC_TRY(need_init());
+    return pool_trim();
+}
+
+// ---------------------------------------------------------------- planes
+int kc_plane_alloc(uint32_t w, uint32_t h, kc_plane **out)
+{
+    KC_ARG(out);
+    return plane_new_mem(w, h, out);
+}
+
+int kc_plane_const(uint32_t w, uint32_t h, float v, kc_plane **out)
+{
+    KC_ARG(out && w > 0 && h > 0);
+    *out = plane_new_const(w, h, v);
+    return KC_OK;
+}
+
+int kc_plane_wrap(void *dptr, uint32_t w, uint32_t h, size_t pitch, kc_plane **out)
+{
+    KC_TRY(need_init());
+    KC_ARG(out && dptr && w > 0 && h > 0);
+    // kernels move 16 bytes per lane: rows must start 16-byte aligned and be readable in whole
+    // float4 units (pitch covers the width rounded up to 4 floats)
+    if (((uintptr_t)dptr & 15) || (pitch & 15) || pitch < ((size_t)(w + 3) / 4) * 16) {
+        set_error("kc_plane_wrap: pointer and pitch must be 16-byte aligned and pitch >= 16*ceil(width/4)");
+        return KC_ERR_INVALID_ARG;
+    }
+    kc_plane *p = new kc_plane();
+    p->w = w;
+    p->h = h;
+    p->kind = kc_plane::MEM;
+    p->dptr = (float *)dptr;
+    p->pitch = pitch;
+    p->owned = false;
+    *out = p;
+    return KC_OK;
+}
+
+int kc_plane_retain(kc_plane *p)
+{
+    KC_ARG(p);
+    plane_retain(p);
+    return KC_OK;
+}
+
+int kc_plane_release(kc_plane *p)
+{
+    if (!p) return KC_OK;
+    Lock lk(ctx().mu);
+    plane_release(p);
+    return KC_OK;
+}
+
+int kc_plane_size(const kc_plane *p, uint32_t *w, uint32_t *h)
+{
+    KC_ARG(p);
+    if (w) *w = p->w;
+    if (h) *h = p->h;
+    return KC_OK;
+}
+
+int kc_plane_is_const(const kc_plane *p, int *is_const, float *v)
+{
+    KC_ARG(p);
+    if (is_const) *is_const = p->kind == kc_plane::CONST;
+    if (v) *v = p->cval;
+    return KC_OK;
+}
+
+int kc_plane_materialize(kc_plane *p)
+{
+    KC_ARG(p);
+    return plane_materialize(p);
+}
+
+int kc_plane_device_ptr(kc_plane *p, void **dptr, size_t *pitch)
+{
+    KC_ARG(p);
+    KC_TRY(plane_materialize(p));
+    if (dptr) *dptr = p->dptr;
+    if (pitch) *pitch = p->pitch;
+    return KC_OK;
+}
+
+int kc_plane_upload_f32(kc_plane *p, const float *host, size_t host_pitch)
+{
+    KC_TRY(need_init());
+    KC_ARG(p && host && p->kind == kc_plane::MEM);
+    if (host_pitch == 0) host_pitch = (size_t)p->w * 4;
+    Lock lk(ctx().mu);
+    KC_HIP(hipMemcpy2DAsync(p->dptr, p->pitch, host, host_pitch, (size_t)p->w * 4, p->h, hipMemcpyHostToDevice, ctx().stream));
+    KC_HIP(hipStreamSynchronize(ctx().stream));
+    return KC_OK;
+}
+
+int kc_plane_download_f32(kc_plane *p, float *host, size_t host_pitch)
+{
+    KC_ARG(p && host);
+    if (host_pitch == 0) host_pitch = (size_t)p->w * 4;
+    Lock lk(ctx().mu);
+    if (p->kind == kc_plane::CONST) {
+        for (uint32_t y = 0; y < p->h; ++y) {
+            float *row = (float *)((char *)host + y * host_pitch);
+            for (uint32_t x = 0; x < p->w; ++x) row[x] = p->cval;
+        }
+        return KC_OK;
+    }
+    KC_TRY(need_init());
+    KC_TRY(plane_force(p));
+    KC_HIP(hipMemcpy2DAsync(host, host_pitch, p->dptr, p->pitch, (size_t)p->w * 4, p->h, hipMemcpyDeviceToHost, ctx().stream));
+    KC_HIP(hipStreamSynchronize(ctx().stream));
+    return KC_OK;
+}
+
+// ---------------------------------------------------------------- images
+int kc_image_gray(kc_plane *p, kc_image **out)
+{
+    KC_ARG(p && out);
+    *out = image_new(1, &p);
+    return KC_OK;
+}
+
+int kc_image_rgba(kc_plane *const planes[4], kc_image **out)
+{
+    KC_ARG(planes && out && planes[0] && planes[1] && planes[2] && planes[3]);
+    for (int i = 1; i < 4; ++i) KC_ARG(planes[i]->w == planes[0]->w && planes[i]->h == planes[0]->h);
+    *out = image_new(4, planes);
+    return KC_OK;
+}
+
+int kc_image_retain(kc_image *img)
+{
+    KC_ARG(img);
+    image_retain(img);
+    return KC_OK;
+}
+
+int kc_image_release(kc_image *img)
+{
+    if (!img) return KC_OK;
+    Lock lk(ctx().mu);
+    image_release(img);
+    return KC_OK;
+}
+
+int kc_image_is_rgba(const kc_image *img, int *is_rgba)
+{
+    KC_ARG(img && is_rgba);
+    *is_rgba = img->is_rgba();
+    return KC_OK;
+}
+
+int kc_image_size(const kc_image *img, kc_size *size)
+{
+    KC_ARG(img && size);
+    *size = kc_size{ img->w(), img->h() };
+    return KC_OK;
+}
+
+int kc_image_plane(const kc_image *img, int channel, kc_plane **out)
+{
+    KC_ARG(img && out && channel >= 0 && channel < img->n);
+    *out = img->planes[channel];
+    plane_retain(*out);
+    return KC_OK;
+}
+
+int kc_image_from_value(kc_size size, float v, int rgba, kc_image **out)
+{
+    KC_ARG(out);
+    return image_from_value(size, v, rgba != 0, out);
+}
+
+int kc_image_as_type(const kc_image *img, int rgba, kc_image **out)
+{
+    KC_ARG(img && out);
+    return image_as_type(const_cast<kc_image *>(img), rgba != 0, out);
+}
+
+int kc_image_materialize(kc_image *img)
+{
+    KC_ARG(img);
+    Lock lk(ctx().mu);
+    KC_TRY(image_force(img));
+    for (int i = 0; i < img->n; ++i) KC_TRY(plane_materialize(img->planes[i]));
+    return KC_OK;
+}
+
+int kc_image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_image **out)
+{
+    KC_ARG(out);
+    int s = image_from_u8(host, w, h, channels, out);
+    if (s == KC_OK) KC_HIP(hipStreamSynchronize(ctx().stream));  // host buffer may be reused on return
+    return s;
+}
+
+int kc_image_to_u8(kc_image *img, int srgb, uint8_t *host)
+{
+    KC_ARG(img && host);
+    return image_to_u8(img, srgb != 0, host);
+}
+
+int kc_image_from_f32(const float *const host_planes[], int n, uint32_t w, uint32_t h, kc_image **out)
+{
+    KC_ARG(host_planes && out && (n == 1 || n == 4));
+    kc_plane *p[4] = { nullptr, nullptr, nullptr, nullptr };
+    int s = KC_OK;
+    for (int i = 0; i < n && s == KC_OK; ++i) {
+        s = plane_new_mem(w, h, &p[i]);
+        if (s == KC_OK) s = kc_plane_upload_f32(p[i], host_planes[i], 0);
+    }
+    if (s == KC_OK) *out = image_new(n, p);
+    for (int i = 0; i < n; ++i) plane_release(p[i]);
+    return s;
+}
+
+int kc_image_to_f32(kc_image *img, float *const host_planes[], int n)
+{
+    KC_ARG(img && host_planes && n == img->n);
+    Lock lk(ctx().mu);
+    KC_TRY(image_force(img));  // one batched launch for R, G, B
+    for (int i = 0; i < n; ++i) KC_TRY(kc_plane_download_f32(img->planes[i], host_planes[i], 0));
+    return KC_OK;
+}
+
+int kc_image_read_png(const char *path, kc_image **out)
+{
+    KC_ARG(path && out);
+    std::vector<uint8_t> px;
+    uint32_t w = 0, h = 0;
+    int ch = 0;
+    KC_TRY(png_read(path, px, w, h, ch));
+    return kc_image_from_u8(px.data(), w, h, ch, out);
+}
+
+int kc_image_write_png(kc_image *img, const char *path)
+{
+    KC_ARG(img && path);
+    std::vector<uint8_t> px((size_t)img->w() * img->h() * 4);
+    KC_TRY(image_to_u8(img, false, px.data()));
+    return png_write_rgba8(path, px.data(), img->w(), img->h());
+}
+
+// ---------------------------------------------------------------- operators
+int kc_calculate_size(int policy, const kc_size *sizes, int n, int slot_index, kc_size specific, kc_size *out)
+{
+    KC_ARG(out && (n == 0 || sizes));
+    return calculate_size(policy, sizes, n, slot_index, specific, out);
+}
+
+int kc_resize_image(kc_image *src, kc_size size, int filter, kc_image **out)
+{
+    KC_ARG(src && out);
+    return resize_image(src, size, filter, out);
+}
+
+int kc_resize_buffers(kc_image *const images[], const kc_edge keys[], int n, const kc_edge *edges_sorted, int n_edges,
+                      int policy, uint32_t policy_slot, kc_size policy_size, int filter, kc_image *out[])
+{
+    KC_ARG(n >= 0 && (n == 0 || (images && keys && out)));
+    if (n == 0) return KC_OK;  // shared.rs:147-149
+    std::vector<kc_size> sizes;
+    for (int i = 0; i < n; ++i) sizes.push_back(kc_size{ images[i]->w(), images[i]->h() });
+    int slot_index = -1;
+    if (policy == KC_POLICY_SPECIFIC_SLOT && edges_sorted && n_edges > 0) {
+        const kc_edge *edge = nullptr;
+        for (int i = 0; i < n_edges; ++i)
+            if (edges_sorted[i].input_slot == policy_slot) {
+                edge = &edges_sorted[i];
+                break;
+            }
+        if (!edge) edge = &edges_sorted[0];
+        for (int i = 0; i < n; ++i)
+            if (keys[i].output_slot == edge->output_slot && keys[i].output_id == edge->output_id) {
+                slot_index = i;
+                break;
+            }
+    }
+    kc_size size;
+    KC_TRY(calculate_size(policy, sizes.data(), n, slot_index, policy_size, &size));
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    for (int i = 0; i < n; ++i) {
+        if (images[i]->w() != size.width || images[i]->h() != size.height) {
+            int s = resize_image(images[i], size, filter, &out[i]);
+            if (s != KC_OK) {
+                for (int j = 0; j < i; ++j) image_release(out[j]);
+                return s;
+            }
+        } else {
+            out[i] = images[i];
+            image_retain(out[i]);
+        }
+    }
+    return KC_OK;
+}
+
+int kc_mix_process(kc_image *left, kc_image *right, int mix_type, kc_image **out)
+{
+    KC_ARG(out);
+    return mix_process(left, right, mix_type, out);
+}
+
+int kc_separate_rgba_process(kc_image *input, kc_image *out[4])
+{
+    KC_ARG(out);
+    return separate_process(input, out);
+}
+
+int kc_combine_rgba_process(kc_image *const inputs[4], kc_image **out)
+{
+    KC_ARG(inputs && out);
+    return combine_process(inputs, out);
+}
+
+int kc_value_process(float v, kc_image **out)
+{
+    KC_ARG(out);
+    return value_process(v, out);
+}
+
+int kc_height_to_normal_process(kc_image *input, kc_image **out)
+{
+    KC_ARG(out);
+    return height_to_normal_process(input, out);
+}
+
+// ---------------------------------------------------------------- NodeGraph
+int kc_node_graph_new(kc_node_graph **out)
+{
+    KC_ARG(out);
+    *out = new kc_node_graph();
+    return KC_OK;
+}
+
+int kc_node_graph_clone(const kc_node_graph *g, kc_node_graph **out)
+{
+    KC_ARG(g && out);
+    *out = new kc_node_graph(*g);
+    return KC_OK;
+}
+
+int kc_node_graph_free(kc_node_graph *g)
+{
+    delete g;
+    return KC_OK;
+}
+
+int kc_node_graph_from_json(const char *json, kc_node_graph **out)
+{
+    KC_ARG(json && out);
+    kc_node_graph *g = new kc_node_graph();
+    int s = graph_from_json(json, g->g);
+    if (s != KC_OK) {
+        delete g;
+        return s;
+    }
+    *out = g;
+    return KC_OK;
+}
+
+int kc_node_graph_from_path(const char *path, kc_node_graph **out)
+{
+    KC_ARG(path && out);
+    std::ifstream f(path);
+    if (!f) {
+        set_error(std::string("cannot open ") + path);
+        return KC_ERR_IO;
+    }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return kc_node_graph_from_json(ss.str().c_str(), out);
+}
+
+int kc_node_graph_to_json(const kc_node_graph *g, char *buf, size_t cap, size_t *needed)
+{
+    KC_ARG(g);
+    std::string s = graph_to_json(g->g);
+    if (needed) *needed = s.size() + 1;
+    if (buf && cap > 0) {
+        size_t n = std::min(cap - 1, s.size());
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return KC_OK;
+}
+
+int kc_node_graph_export_json(const kc_node_graph *g, const char *path)
+{
+    KC_ARG(g && path);
+    std::ofstream f(path);
+    if (!f) {
+        set_error(std::string("cannot create ") + path);
+        return KC_ERR_IO;
+    }
+    f << graph_to_json(g->g);
+    return f.good() ? KC_OK : KC_ERR_IO;
+}
+
+int kc_node_graph_add_node(kc_node_graph *g, const kc_node_desc *node, uint32_t *id)
+{
+    KC_ARG(g && node);
+    return g->g.add_node(node_from_desc(*node), id);
+}
+
+int kc_node_graph_add_node_with_id(kc_node_graph *g, const kc_node_desc *node)
+{
+    KC_ARG(g && node);
+    return g->g.add_node_with_id(node_from_desc(*node));
+}
+
+int kc_node_graph_connect(kc_node_graph *g, uint32_t on, uint32_t in, uint32_t os, uint32_t is)
+{
+    KC_ARG(g);
+    return g->g.connect(on, in, os, is);
+}
+
+int kc_node_graph_try_connect(kc_node_graph *g, uint32_t on, uint32_t in, uint32_t os, uint32_t is)
+{
+    KC_ARG(g);
+    return g->g.try_connect(on, in, os, is);
+}
+
+int kc_node_graph_remove_node(kc_node_graph *g, uint32_t id)
+{
+    KC_ARG(g);
+    return g->g.remove_node(id, nullptr);
+}
+
+int kc_node_graph_remove_edge(kc_node_graph *g, kc_edge e)
+{
+    KC_ARG(g);
+    return g->g.remove_edge(e);
+}
+
+int kc_node_graph_disconnect_slot(kc_node_graph *g, uint32_t id, int side, uint32_t slot)
+{
+    KC_ARG(g);
+    return g->g.disconnect_slot(id, side, slot, nullptr);
+}
+
+int kc_node_graph_node_count(const kc_node_graph *g, uint32_t *count)
+{
+    KC_ARG(g && count);
+    *count = (uint32_t)g->g.nodes.size();
+    return KC_OK;
+}
+
+static int copy_ids(const std::vector<uint32_t> &v, uint32_t *ids, uint32_t cap, uint32_t *count)
+{
+    if (count) *count = (uint32_t)v.size();
+    if (ids)
+        for (uint32_t i = 0; i < cap && i < v.size(); ++i) ids[i] = v[i];
+    return KC_OK;
+}
+
+static int copy_edges(const std::vector<kc_edge> &v, kc_edge *edges, uint32_t cap, uint32_t *count)
+{
+    if (count) *count = (uint32_t)v.size();
+    if (edges)
+        for (uint32_t i = 0; i < cap && i < v.size(); ++i) edges[i] = v[i];
+    return KC_OK;
+}
+
+int kc_node_graph_node_ids(const kc_node_graph *g, uint32_t *ids, uint32_t cap, uint32_t *count)
+{
+    KC_ARG(g);
+    std::vector<uint32_t> v;
+    for (auto &n : g->g.nodes) v.push_back(n.node_id);
+    return copy_ids(v, ids, cap, count);
+}
+
+int kc_node_graph_edges(const kc_node_graph *g, kc_edge *edges, uint32_t cap, uint32_t *count)
+{
+    KC_ARG(g);
+    return copy_edges(g->g.edges, edges, cap, count);
+}
+
+int kc_node_graph_input_slot_id_with_name(const kc_node_graph *g, const char *name, uint32_t *slot)
+{
+    KC_ARG(g && name && slot);
+    for (auto &n : g->g.nodes)
+        if (n.is_input() && n.text == name) {
+            *slot = n.node_id;
+            return KC_OK;
+        }
+    return KC_ERR_INVALID_NAME;
+}
+
+int kc_node_graph_output_slot_id_with_name(const kc_node_graph *g, const char *name, uint32_t *slot)
+{
+    KC_ARG(g && name && slot);
+    for (auto &n : g->g.nodes)
+        if (n.is_output() && n.text == name) {
+            *slot = n.node_id;
+            return KC_OK;
+        }
+    return KC_ERR_INVALID_NAME;
+}
+
+int kc_node_graph_set_mix_type(kc_node_graph *g, uint32_t id, int mix)
+{
+    KC_ARG(g && mix >= KC_MIX_ADD && mix <= KC_MIX_POW);
+    Node *n = g->g.find(id);
+    if (!n || n->type != KC_NODE_MIX) return KC_ERR_INVALID_NODE_ID;
+    n->mix_type = mix;
+    return KC_OK;
+}
+
+// ---------------------------------------------------------------- TextureProcessor / LiveGraph
+int kc_tex_pro_new(uint64_t memory_threshold, kc_tex_pro **out)
+{
+    KC_ARG(out);
+    kc_tex_pro *tp = new kc_tex_pro();
+    tp->memory_threshold = memory_threshold;
+    *out = tp;
+    return KC_OK;
+}
+
+int kc_tex_pro_free(kc_tex_pro *tp)
+{
+    delete tp;
+    return KC_OK;
+}
+
+int kc_tex_pro_new_live_graph(kc_tex_pro *tp, kc_live_graph **out)
+{
+    KC_ARG(tp && out);
+    kc_live_graph *lg = new kc_live_graph();
+    lg->tp = tp;
+    *out = lg;
+    return KC_OK;
+}
+
+int kc_live_graph_free(kc_live_graph *lg)
+{
+    if (!lg) return KC_OK;
+    Lock lk(ctx().mu);
+    delete lg;
+    return KC_OK;
+}
+
+#define LG_LOCK(lg) KC_ARG(lg); Lock _ctx_lock(ctx().mu)
+
+int kc_live_graph_set_flags(kc_live_graph *lg, int auto_update, int use_cache)
+{
+    LG_LOCK(lg);
+    lg->auto_update = auto_update != 0;
+    lg->use_cache = use_cache != 0;
+    return KC_OK;
+}
+
+int kc_live_graph_get_flags(const kc_live_graph *lg, int *auto_update, int *use_cache)
+{
+    KC_ARG(lg);
+    if (auto_update) *auto_update = lg->auto_update;
+    if (use_cache) *use_cache = lg->use_cache;
+    return KC_OK;
+}
+
+int kc_live_graph_set_node_graph(kc_live_graph *lg, const kc_node_graph *g)
+{
+    LG_LOCK(lg);
+    KC_ARG(g);
+    lg->g = g->g;
+    lg->reset_node_states();
+    lg->clear_data();
+    return KC_OK;
+}
+
+int kc_live_graph_node_graph(const kc_live_graph *lg, kc_node_graph **out)
+{
+    KC_ARG(lg && out);
+    kc_node_graph *g = new kc_node_graph();
+    g->g = lg->g;
+    *out = g;
+    return KC_OK;
+}
+
+int kc_live_graph_add_node(kc_live_graph *lg, const kc_node_desc *node, uint32_t *id)
+{
+    LG_LOCK(lg);
+    KC_ARG(node);
+    return lg->add_node(node_from_desc(*node), id);
+}
+
+int kc_live_graph_add_node_with_id(kc_live_graph *lg, const kc_node_desc *node)
+{
+    LG_LOCK(lg);
+    KC_ARG(node);
+    return lg->add_node_with_id(node_from_desc(*node));
+}
+
+int kc_live_graph_remove_node(kc_live_graph *lg, uint32_t id)
+{
+    LG_LOCK(lg);
+    return lg->remove_node(id);
+}
+
+int kc_live_graph_connect(kc_live_graph *lg, uint32_t on, uint32_t in, uint32_t os, uint32_t is)
+{
+    LG_LOCK(lg);
+    return lg->connect(on, in, os, is);
+}
+
+int kc_live_graph_remove_edge(kc_live_graph *lg, kc_edge e)
+{
+    LG_LOCK(lg);
+    return lg->remove_edge(e);
+}
+
+int kc_live_graph_disconnect_slot(kc_live_graph *lg, uint32_t id, int side, uint32_t slot)
+{
+    LG_LOCK(lg);
+    return lg->disconnect_slot(id, side, slot);
+}
+
+int kc_live_graph_set_mix_type(kc_live_graph *lg, uint32_t id, int mix)
+{
+    LG_LOCK(lg);
+    KC_ARG(mix >= KC_MIX_ADD && mix <= KC_MIX_POW);
+    Node *n = lg->g.find(id);
+    if (!n) return KC_ERR_INVALID_NODE_ID;
+    KC_TRY(lg->set_state(id, KC_STATE_DIRTY));  // node_mut, :369-374
+    if (n->type != KC_NODE_MIX) return KC_ERR_INVALID_NODE_TYPE;
+    n->mix_type = mix;
+    return KC_OK;
+}
+
+int kc_live_graph_set_resize(kc_live_graph *lg, uint32_t id, int policy, uint32_t slot, kc_size size, int filter)
+{
+    LG_LOCK(lg);
+    KC_ARG(policy >= 0 && policy <= KC_POLICY_SPECIFIC_SIZE && filter >= 0 && filter <= KC_FILTER_LANCZOS3);
+    Node *n = lg->g.find(id);
+    if (!n) return KC_ERR_INVALID_NODE_ID;
+    KC_TRY(lg->set_state(id, KC_STATE_DIRTY));
+    n->policy = policy;
+    n->policy_slot = slot;
+    n->policy_size = size;
+    n->filter = filter;
+    return KC_OK;
+}
+
+int kc_live_graph_node_state(const kc_live_graph *lg, uint32_t id, int *state)
+{
+    KC_ARG(lg && state);
+    return lg->state_of(id, state);
+}
+
+int kc_live_graph_request(kc_live_graph *lg, uint32_t id)
+{
+    LG_LOCK(lg);
+    int st;
+    KC_TRY(lg->state_of(id, &st));
+    if (st == KC_STATE_DIRTY) lg->node_state[id] = KC_STATE_REQUESTED;
+    return KC_OK;
+}
+
+int kc_live_graph_prioritise(kc_live_graph *lg, uint32_t id)
+{
+    LG_LOCK(lg);
+    int st;
+    KC_TRY(lg->state_of(id, &st));
+    if (st == KC_STATE_DIRTY || st == KC_STATE_REQUESTED) lg->node_state[id] = KC_STATE_PRIORITISED;
+    return KC_OK;
+}
+
+int kc_live_graph_await_clean(kc_live_graph *lg, uint32_t id)
+{
+    LG_LOCK(lg);
+    return lg->await_clean(id);
+}
+
+int kc_live_graph_update(kc_live_graph *lg)
+{
+    LG_LOCK(lg);
+    return lg->update();
+}
+
+int kc_live_graph_slot_data(kc_live_graph *lg, uint32_t node, uint32_t slot, kc_image **out)
+{
+    LG_LOCK(lg);
+    KC_ARG(out);
+    const SlotData *sd = lg->find_slot(node, slot);
+    if (!sd) return KC_ERR_NO_SLOT_DATA;
+    image_retain(sd->image);
+    *out = sd->image;
+    return KC_OK;
+}
+
+int kc_live_graph_slot_data_size(kc_live_graph *lg, uint32_t node, uint32_t slot, kc_size *size)
+{
+    LG_LOCK(lg);
+    KC_ARG(size);
+    const SlotData *sd = lg->find_slot(node, slot);
+    if (!sd) return KC_ERR_NO_SLOT_DATA;
+    *size = kc_size{ sd->image->w(), sd->image->h() };
+    return KC_OK;
+}
+
+int kc_live_graph_slot_in_memory(kc_live_graph *lg, uint32_t node, uint32_t slot, int *in_memory)
+{
+    LG_LOCK(lg);
+    KC_ARG(in_memory);
+    if (!lg->find_slot(node, slot)) return KC_ERR_NO_SLOT_DATA;
+    *in_memory = 1;  // planes never leave HBM: there is no disk tier to page out to
+    return KC_OK;
+}
+
+int kc_live_graph_node_slot_ids(kc_live_graph *lg, uint32_t node, uint32_t *slots, uint32_t cap, uint32_t *count)
+{
+    LG_LOCK(lg);
+    std::vector<uint32_t> v;
+    for (auto &sd : lg->slot_datas)
+        if (sd.node_id == node) v.push_back(sd.slot_id);
+    return copy_ids(v, slots, cap, count);
+}
+
+int kc_live_graph_buffer_rgba(kc_live_graph *lg, uint32_t node, uint32_t slot, int srgb, uint8_t *host)
+{
+    LG_LOCK(lg);
+    KC_ARG(host);
+    const SlotData *sd = lg->find_slot(node, slot);
+    if (!sd) return KC_ERR_NO_SLOT_DATA;
+    return image_to_u8(sd->image, srgb != 0, host);
+}
+
+int kc_live_graph_embed_slot_data_with_id(kc_live_graph *lg, kc_image *image, uint32_t slot_id, uint32_t embed_id)
+{
+    LG_LOCK(lg);
+    KC_ARG(image);
+    for (auto &e : lg->embedded)
+        if (e.slot_data_id == embed_id) return KC_ERR_INVALID_SLOT_ID;  // :329-340
+    image_retain(image);
+    lg->embedded.push_back(EmbeddedSlotData{ embed_id, slot_id, image });
+    return KC_OK;
+}
+
+int kc_live_graph_add_input_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image *image)
+{
+    LG_LOCK(lg);
+    KC_ARG(image);
+    image_retain(image);
+    lg->input_slot_datas.push_back(SlotData{ node_id, slot_id, image });
+    return KC_OK;
+}
+
+int kc_live_graph_changed_consume(kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count)
+{
+    LG_LOCK(lg);
+    std::vector<uint32_t> v(lg->changed.begin(), lg->changed.end());
+    if (ids && cap >= v.size()) lg->changed.clear();  // a NULL / short buffer only queries the count
+    return copy_ids(v, ids, cap, count);
+}
+
+int kc_live_graph_output_ids(const kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count)
+{
+    KC_ARG(lg);
+    return copy_ids(lg->g.output_ids(), ids, cap, count);
+}
+
+int kc_live_graph_node_ids(const kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count)
+{
+    KC_ARG(lg);
+    std::vector<uint32_t> v;
+    for (auto &n : lg->g.nodes) v.push_back(n.node_id);
+    return copy_ids(v, ids, cap, count);
+}
+
+int kc_live_graph_edges(const kc_live_graph *lg, kc_edge *edges, uint32_t cap, uint32_t *count)
+{
+    KC_ARG(lg);
+    return copy_edges(lg->g.edges, edges, cap, count);
+}
+
+int kc_live_graph_set_base_dir(kc_live_graph *lg, const char *dir)
+{
+    LG_LOCK(lg);
+    lg->base_dir = dir ? dir : "";
+    return KC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// Internal declarations shared by the HIP kernels (kernels.hip) and the host runtime.
+// Not part of the C ABI (include/kanter_core_amd.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kanter_core_amd.h"
+
+namespace kc {
+
+// ------------------------------------------------------------------------------------------
+// Fused pointwise chain: acc = start; for each step acc = op(acc, x) or op(x, acc).
+// One program drives up to KC_CHAIN_MAX_BATCH planes (the R, G, B planes of an RGBA Mix share
+// ops but not operands), blockIdx.y selects the plane.
+// ------------------------------------------------------------------------------------------
+constexpr int KC_CHAIN_MAX_OPS = 64;
+constexpr int KC_CHAIN_MAX_IN = 4;
+constexpr int KC_CHAIN_MAX_BATCH = 4;
+
+// Step codes: which side the running value sits on matters for -, / and pow.
+enum ChainCode : uint8_t {
+    CH_ADD = 0,    // acc + x
+    CH_SUB_L = 1,  // acc - x
+    CH_SUB_R = 2,  // x - acc
+    CH_MUL = 3,    // acc * x
+    CH_DIV_L = 4,  // acc / x
+    CH_DIV_R = 5,  // x / acc
+    CH_POW_L = 6,  // acc ^ x
+    CH_POW_R = 7,  // x ^ acc
+    CH_ADD_R = 8,  // x + acc (kept distinct so NaN payload order matches l + r)
+    CH_MUL_R = 9   // x * acc
+};
+
+struct ChainProgram {
+    uint32_t n_ops;
+    uint32_t n_in;
+    uint32_t row_units;  // vector units (float4 or float) per row; rows * row_units = work items
+    uint32_t rows;
+    int32_t start_src;  // input index, or -1: start from start_c
+    uint8_t code[KC_CHAIN_MAX_OPS];
+    int8_t src[KC_CHAIN_MAX_OPS];  // input index, or -1: constant c[b][i]
+    const float *in[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];
+    uint32_t in_pitch[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];  // in vector units
+    float *out[KC_CHAIN_MAX_BATCH];
+    uint32_t out_pitch[KC_CHAIN_MAX_BATCH];
+    float start_c[KC_CHAIN_MAX_BATCH];
+    float c[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_OPS];
+};
+
+// Per-axis tap table of the separable resampler, resident in HBM.
+struct TapsDev {
+    const uint32_t *left;
+    const uint32_t *count;
+    const float *w;
+    uint32_t stride;
+};
+
+// Pointwise operand: a pitched plane or a broadcast constant.
+struct Operand {
+    const float *ptr;  // nullptr => constant
+    uint32_t pitch;    // in floats
+    float c;
+};
+
+// ---- kernel launchers (kernels.hip).  All enqueue on `s` and return hipGetLastError(). ----
+hipError_t launch_chain(const ChainProgram &p, int batch, bool has_pow, int max_blocks, hipStream_t s);
+hipError_t launch_fill(float *dst, uint32_t pitch_floats, uint32_t w, uint32_t h, float v, hipStream_t s);
+hipError_t launch_resize_vertical(const float *src, uint32_t spitch, uint32_t sw, float *tmp, uint32_t tpitch,
+                                  uint32_t dh, TapsDev v, hipStream_t s);
+hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *dst, uint32_t dpitch, uint32_t dw,
+                                    uint32_t dh, TapsDev h, hipStream_t s);
+// LDS-tiled single-pass resample; `ncap` = widest source-column window of any tile (from host).
+hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
+                             uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncap,
+                             hipStream_t s);
+hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, float *nx, float *ny,
+                                   float *nz, uint32_t opitch, hipStream_t s);
+hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,
+                        uint8_t *dst, hipStream_t s);
+hipError_t launch_from_u8(const uint8_t *src, int channels, uint32_t w, uint32_t h, float *const planes[4],
+                          uint32_t pitch, hipStream_t s);
+
+}  // namespace kc

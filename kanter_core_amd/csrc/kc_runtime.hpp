@@ -1,0 +1,261 @@
+// Host runtime declarations: context, HBM plane pool, planes / images, node operators, graphs.
+#pragma once
+
+#include <deque>
+#include <set>
+#include <tuple>
+
+#include "kc_internal.hpp"
+
+// ------------------------------------------------------------------------------------------
+// Opaque C-ABI types
+// ------------------------------------------------------------------------------------------
+namespace kc {
+struct Chain;
+}
+
+// One channel.  MEM: pitched f32 in HBM.  CONST: broadcast scalar (what the reference holds as
+// vec![v; n]).  LAZY: a pointwise Mix chain that has not been run yet; forcing it launches the
+// fused chain kernel and turns the plane into MEM.
+struct kc_plane {
+    enum Kind { MEM = 0, CONST = 1, LAZY = 2 };
+    std::atomic<int> refs{ 1 };
+    uint32_t w = 0, h = 0;
+    Kind kind = MEM;
+    float *dptr = nullptr;
+    size_t pitch = 0;  // bytes
+    size_t bytes = 0;  // pool block size (owned planes)
+    bool owned = false;
+    float cval = 0.0f;
+    kc::Chain *chain = nullptr;
+};
+
+// SlotImage, src/slot_image.rs:15-19
+struct kc_image {
+    std::atomic<int> refs{ 1 };
+    int n = 0;  // 1 = Gray, 4 = Rgba
+    kc_plane *planes[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool is_rgba() const { return n == 4; }
+    uint32_t w() const { return planes[0]->w; }
+    uint32_t h() const { return planes[0]->h; }
+};
+
+namespace kc {
+
+struct ChainStep {
+    uint8_t code;       // ChainCode
+    kc_plane *operand;  // retained; MEM or CONST
+};
+
+struct Chain {
+    kc_plane *start = nullptr;  // retained; MEM or CONST
+    std::vector<ChainStep> steps;
+    ~Chain();
+};
+
+struct TapsHost {
+    std::vector<uint32_t> left, count;
+    std::vector<float> w;
+    uint32_t stride = 1;
+};
+
+struct TapsEntry {
+    TapsHost host;
+    void *dev_block = nullptr;
+    size_t dev_bytes = 0;
+    TapsDev dev{};
+};
+
+struct Context {
+    std::recursive_mutex mu;
+    bool inited = false;
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool fusion = true;
+    int max_blocks = 4096;
+    bool resize_two_pass = false;
+    std::multimap<size_t, void *> free_blocks;
+    uint64_t bytes_in_use = 0, bytes_cached = 0, launches = 0;
+    std::map<std::tuple<uint32_t, uint32_t, int>, TapsEntry> taps;
+};
+
+Context &ctx();
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);  // records the message, returns KC_ERR_HIP
+int need_init();                               // KC_OK or KC_ERR_NO_DEVICE
+
+#define KC_HIP(call)                                           \
+    do {                                                       \
+        hipError_t _e = (call);                                \
+        if (_e != hipSuccess) return kc::hip_fail(_e, #call);  \
+    } while (0)
+#define KC_TRY(expr)                   \
+    do {                               \
+        int _s = (expr);               \
+        if (_s != KC_OK) return _s;    \
+    } while (0)
+
+// ---- pool / planes (runtime.cpp) ----
+int pool_alloc(size_t bytes, void **out);
+void pool_free(void *p, size_t bytes);
+int pool_trim();
+
+int plane_new_mem(uint32_t w, uint32_t h, kc_plane **out);
+kc_plane *plane_new_const(uint32_t w, uint32_t h, float v);
+void plane_retain(kc_plane *p);
+void plane_release(kc_plane *p);
+int plane_force(kc_plane *p);                           // LAZY -> MEM (CONST stays CONST)
+int planes_force(kc_plane *const *planes, int n);       // batches chains that share a program
+int plane_materialize(kc_plane *p);                     // LAZY/CONST -> MEM
+// l op r for one channel (src/node/mix.rs:136-192): lazy chain, constant fold or immediate kernel.
+int plane_mix(int mix_type, kc_plane *l, kc_plane *r, kc_plane **out);
+Operand plane_operand(const kc_plane *p);               // MEM or CONST only
+
+kc_image *image_new(int n, kc_plane *const *planes);    // retains the planes
+void image_retain(kc_image *img);
+void image_release(kc_image *img);
+int image_force(kc_image *img);
+
+// ---- node operators (ops.cpp) ----
+int image_from_value(kc_size size, float v, bool rgba, kc_image **out);
+int image_as_type(kc_image *img, bool rgba, kc_image **out);
+int image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_image **out);
+int image_to_u8(kc_image *img, bool srgb, uint8_t *host);
+int calculate_size(int policy, const kc_size *sizes, int n, int slot_index, kc_size specific, kc_size *out);
+int mix_process(kc_image *left, kc_image *right, int mix_type, kc_image **out);
+int separate_process(kc_image *in, kc_image *out[4]);
+int combine_process(kc_image *const in[4], kc_image **out);
+int value_process(float v, kc_image **out);
+int height_to_normal_process(kc_image *in, kc_image **out);
+
+// ---- resize (resize.cpp) ----
+int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t);
+int resize_image(kc_image *src, kc_size size, int filter, kc_image **out);
+
+// ---- png / json (png.cpp, json.cpp) ----
+int png_read(const std::string &path, std::vector<uint8_t> &px, uint32_t &w, uint32_t &h, int &channels);
+int png_write_rgba8(const std::string &path, const uint8_t *px, uint32_t w, uint32_t h);
+
+// ------------------------------------------------------------------------------------------
+// Graph model: src/node_graph.rs, src/node/mod.rs:113-123, src/edge.rs
+// ------------------------------------------------------------------------------------------
+struct NodeGraph;
+
+struct Node {
+    uint32_t node_id = 0;
+    int type = KC_NODE_VALUE;
+    int mix_type = KC_MIX_ADD;
+    float value = 0.0f;
+    uint32_t embed_id = 0;
+    std::string text;                  // Input/Output name, Image/Write path
+    std::shared_ptr<NodeGraph> graph;  // Graph node
+    int policy = KC_POLICY_MOST_PIXELS;
+    uint32_t policy_slot = 0;
+    kc_size policy_size{ 0, 0 };
+    int filter = KC_FILTER_TRIANGLE;
+
+    bool is_input() const { return type == KC_NODE_INPUT_GRAY || type == KC_NODE_INPUT_RGBA; }
+    bool is_output() const { return type == KC_NODE_OUTPUT_GRAY || type == KC_NODE_OUTPUT_RGBA; }
+};
+
+enum SlotType { SLOT_GRAY = 0, SLOT_RGBA = 1, SLOT_GRAY_OR_RGBA = 2 };
+struct Slot {
+    std::string name;
+    uint32_t slot_id;
+    int slot_type;
+};
+
+struct NodeGraph {
+    std::vector<Node> nodes;
+    std::vector<kc_edge> edges;
+    uint32_t node_id_counter = 0;
+
+    const Node *find(uint32_t id) const;
+    Node *find(uint32_t id);
+    uint32_t new_id();
+    int add_node(Node n, uint32_t *id);
+    int add_node_with_id(Node n);
+    int connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is);
+    int try_connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is);
+    int remove_edge(kc_edge e);
+    int remove_node(uint32_t id, std::vector<kc_edge> *removed);
+    int disconnect_slot(uint32_t id, int side, uint32_t slot, std::vector<kc_edge> *removed);
+    std::vector<uint32_t> get_children(uint32_t id) const;
+    std::vector<uint32_t> get_children_recursive(uint32_t id) const;
+    std::vector<uint32_t> get_parents(uint32_t id) const;
+    std::vector<uint32_t> output_ids() const;
+    std::vector<Slot> input_slots_of_graph() const;
+    std::vector<Slot> output_slots_of_graph() const;
+};
+
+std::vector<Slot> node_input_slots(const Node &n, bool *unimplemented = nullptr);
+std::vector<Slot> node_output_slots(const Node &n, bool *unimplemented = nullptr);
+Node node_from_desc(const kc_node_desc &d);
+
+int graph_from_json(const std::string &text, NodeGraph &g);
+std::string graph_to_json(const NodeGraph &g);
+
+}  // namespace kc
+
+struct kc_node_graph {
+    kc::NodeGraph g;
+};
+
+namespace kc {
+
+struct SlotData {
+    uint32_t node_id, slot_id;
+    kc_image *image;  // retained
+};
+
+struct EmbeddedSlotData {
+    uint32_t slot_data_id, slot_id;
+    kc_image *image;
+};
+
+}  // namespace kc
+
+struct kc_tex_pro {
+    uint64_t memory_threshold = 0;
+    std::recursive_mutex mu;
+};
+
+struct kc_live_graph {
+    kc_tex_pro *tp = nullptr;
+    kc::NodeGraph g;
+    std::deque<kc::SlotData> slot_datas;
+    std::vector<kc::EmbeddedSlotData> embedded;
+    std::vector<kc::SlotData> input_slot_datas;
+    std::map<uint32_t, int> node_state;
+    std::set<uint32_t> changed;
+    bool auto_update = false;
+    bool use_cache = false;
+    std::string base_dir;
+    int depth = 0;  // nesting depth of Graph nodes (recursion guard)
+
+    ~kc_live_graph();
+    void clear_data();
+    void remove_nodes_data(uint32_t id);
+    const kc::SlotData *find_slot(uint32_t node, uint32_t slot) const;
+    int state_of(uint32_t id, int *st) const;
+    int set_state(uint32_t id, int st);
+    int force_state(uint32_t id, int st);
+    void reset_node_states();
+    int add_node(kc::Node n, uint32_t *id);
+    int add_node_with_id(kc::Node n);
+    int remove_node(uint32_t id);
+    int connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is);
+    int remove_edge(kc_edge e);
+    int disconnect_slot(uint32_t id, int side, uint32_t slot);
+    int ensure_clean(uint32_t id, int depth_guard);
+    int await_clean(uint32_t id);
+    int update();
+    int process_one(uint32_t id);
+};
+
+namespace kc {
+// process_node, src/node/node_type.rs:213-248: inputs in edge insertion order.
+int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData> &inputs,
+                 const std::vector<kc_edge> &edges, std::vector<SlotData> &out);
+}  // namespace kc

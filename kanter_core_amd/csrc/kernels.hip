@@ -1,0 +1,596 @@
+// Hand-written CDNA4 (gfx950) kernels for the kanter_core per-pixel hot path.
+//
+// All of these are HBM-bandwidth-bound pointwise / small-stencil kernels: 16-byte (dwordx4)
+// coalesced row-major accesses on 256-byte-pitched f32 planes, 64-wide wavefronts, no MFMA.
+// Build flags that matter for parity with the reference's scalar Rust loops:
+//   -ffp-contract=off                         no FMA contraction (Rust never fuses a*b+c)
+//   -fhip-fp32-correctly-rounded-divide-sqrt  IEEE f32 divide / sqrt
+//   f32 denormals are not flushed (gfx9 default)
+// Reference paths are relative to the reference checkout.
+#include "kc_internal.hpp"
+
+namespace kc {
+
+static __device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
+
+// f32::powf (src/node/mix.rs:189): evaluated in f64 and rounded once, so the result is the
+// correctly rounded f32 power (<= 1 ulp from any libm powf) and every IEEE special case
+// (pow(x, 0) = 1, pow(1, NaN) = 1, negative base with non-integer exponent = NaN ...) follows
+// the f64 routine's identical rules.
+static __device__ __noinline__ float kc_powf(float a, float b) { return (float)pow((double)a, (double)b); }
+
+template <int CODE>
+static __device__ __forceinline__ float apply1(float acc, float x)
+{
+    if constexpr (CODE == CH_ADD) return acc + x;
+    else if constexpr (CODE == CH_SUB_L) return acc - x;
+    else if constexpr (CODE == CH_SUB_R) return x - acc;
+    else if constexpr (CODE == CH_MUL) return acc * x;
+    else if constexpr (CODE == CH_DIV_L) return acc / x;
+    else if constexpr (CODE == CH_DIV_R) return x / acc;
+    else if constexpr (CODE == CH_POW_L) return kc_powf(acc, x);
+    else if constexpr (CODE == CH_POW_R) return kc_powf(x, acc);
+    else if constexpr (CODE == CH_ADD_R) return x + acc;
+    else return x * acc;
+}
+
+template <int CODE, int U>
+static __device__ __forceinline__ void apply4(float4 (&acc)[U], const float4 (&x)[U])
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc[u].x = apply1<CODE>(acc[u].x, x[u].x);
+        acc[u].y = apply1<CODE>(acc[u].y, x[u].y);
+        acc[u].z = apply1<CODE>(acc[u].z, x[u].z);
+        acc[u].w = apply1<CODE>(acc[u].w, x[u].w);
+    }
+}
+
+template <int CODE, int U>
+static __device__ __forceinline__ void apply4c(float4 (&acc)[U], float c)
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc[u].x = apply1<CODE>(acc[u].x, c);
+        acc[u].y = apply1<CODE>(acc[u].y, c);
+        acc[u].z = apply1<CODE>(acc[u].z, c);
+        acc[u].w = apply1<CODE>(acc[u].w, c);
+    }
+}
+
+// The step code is wave-uniform (it comes from the kernel argument block), so this switch is a
+// scalar branch; each arm is straight-line VALU on the U float4 the thread owns.
+#define KC_SWITCH_CODE(APPLY)                                   \
+    switch (code) {                                             \
+    case CH_ADD: APPLY(CH_ADD); break;                          \
+    case CH_SUB_L: APPLY(CH_SUB_L); break;                      \
+    case CH_SUB_R: APPLY(CH_SUB_R); break;                      \
+    case CH_MUL: APPLY(CH_MUL); break;                          \
+    case CH_DIV_L: APPLY(CH_DIV_L); break;                      \
+    case CH_DIV_R: APPLY(CH_DIV_R); break;                      \
+    case CH_ADD_R: APPLY(CH_ADD_R); break;                      \
+    case CH_MUL_R: APPLY(CH_MUL_R); break;                      \
+    case CH_POW_L: if constexpr (POW) { APPLY(CH_POW_L); } break; \
+    case CH_POW_R: if constexpr (POW) { APPLY(CH_POW_R); } break; \
+    default: break;                                             \
+    }
+
+// Fused Mix chain (src/node/mix.rs:136-192 applied N times without materialising the
+// intermediates).  K = distinct input planes, U = float4 per thread per iteration, POW = chain
+// contains a pow step (keeps the f64 pow out of the lean instantiations).
+// Algorithmic HBM bytes per pixel: 4 * (planes read + 1 written), whatever N is.
+template <int K, int U, bool POW>
+__global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t total = P.rows * P.row_units;
+    const bool flat = P.rows == 1;
+    const float4 *inp[K];
+    uint32_t ipitch[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        inp[k] = reinterpret_cast<const float4 *>(P.in[b][k]);
+        ipitch[k] = P.in_pitch[b][k];
+    }
+    float4 *outp = reinterpret_cast<float4 *>(P.out[b]);
+    const uint32_t opitch = P.out_pitch[b];
+    const uint32_t step = gridDim.x * (256u * U);
+
+    for (uint32_t base = blockIdx.x * (256u * U) + threadIdx.x; base < total; base += step) {
+        float4 in[K][U];
+        float4 acc[U];
+        uint32_t ooff[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t idx = base + u * 256u;
+            valid[u] = idx < total;
+            uint32_t row = 0, col = idx;
+            if (!flat) {
+                row = idx / P.row_units;
+                col = idx - row * P.row_units;
+            }
+            ooff[u] = row * opitch + col;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                in[k][u] = valid[u] ? inp[k][row * ipitch[k] + col] : splat4(0.0f);
+        }
+
+        if (P.start_src < 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = splat4(P.start_c[b]);
+        } else {
+            switch (P.start_src) {
+            case 0:
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = in[0][u];
+                break;
+            case 1:
+                if constexpr (K > 1) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[u] = in[1][u];
+                }
+                break;
+            case 2:
+                if constexpr (K > 2) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[u] = in[2][u];
+                }
+                break;
+            default:
+                if constexpr (K > 3) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[u] = in[3][u];
+                }
+                break;
+            }
+        }
+
+        for (uint32_t i = 0; i < P.n_ops; ++i) {
+            const int code = P.code[i];
+            const int src = P.src[i];
+            if (src < 0) {
+                const float c = P.c[b][i];
+#define KC_APPLY_C(CODE) apply4c<CODE, U>(acc, c)
+                KC_SWITCH_CODE(KC_APPLY_C)
+#undef KC_APPLY_C
+            } else if (src == 0) {
+#define KC_APPLY_0(CODE) apply4<CODE, U>(acc, in[0])
+                KC_SWITCH_CODE(KC_APPLY_0)
+#undef KC_APPLY_0
+            } else if (src == 1) {
+                if constexpr (K > 1) {
+#define KC_APPLY_1(CODE) apply4<CODE, U>(acc, in[1])
+                    KC_SWITCH_CODE(KC_APPLY_1)
+#undef KC_APPLY_1
+                }
+            } else if (src == 2) {
+                if constexpr (K > 2) {
+#define KC_APPLY_2(CODE) apply4<CODE, U>(acc, in[2])
+                    KC_SWITCH_CODE(KC_APPLY_2)
+#undef KC_APPLY_2
+                }
+            } else {
+                if constexpr (K > 3) {
+#define KC_APPLY_3(CODE) apply4<CODE, U>(acc, in[3])
+                    KC_SWITCH_CODE(KC_APPLY_3)
+#undef KC_APPLY_3
+                }
+            }
+        }
+
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (valid[u]) outp[ooff[u]] = acc[u];
+    }
+}
+
+// Zero-input chain (constant start, constant operands only): still one pass of stores.
+template <int U, bool POW>
+__global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t total = P.rows * P.row_units;
+    const bool flat = P.rows == 1;
+    float4 *outp = reinterpret_cast<float4 *>(P.out[b]);
+    const uint32_t opitch = P.out_pitch[b];
+    float4 acc[1];
+    acc[0] = splat4(P.start_c[b]);
+    for (uint32_t i = 0; i < P.n_ops; ++i) {
+        const int code = P.code[i];
+        const float c = P.c[b][i];
+#define KC_APPLY_C(CODE) apply4c<CODE, 1>(acc, c)
+        KC_SWITCH_CODE(KC_APPLY_C)
+#undef KC_APPLY_C
+    }
+    const uint32_t step = gridDim.x * 256u;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += step) {
+        uint32_t row = 0, col = idx;
+        if (!flat) {
+            row = idx / P.row_units;
+            col = idx - row * P.row_units;
+        }
+        outp[row * opitch + col] = acc[0];
+    }
+}
+
+template <int U, bool POW>
+static hipError_t launch_chain_k(const ChainProgram &p, dim3 grid, hipStream_t s)
+{
+    switch (p.n_in) {
+    case 0: chain_kernel_k0<U, POW><<<grid, 256, 0, s>>>(p); break;
+    case 1: chain_kernel<1, U, POW><<<grid, 256, 0, s>>>(p); break;
+    case 2: chain_kernel<2, U, POW><<<grid, 256, 0, s>>>(p); break;
+    case 3: chain_kernel<3, U, POW><<<grid, 256, 0, s>>>(p); break;
+    case 4: chain_kernel<4, U, POW><<<grid, 256, 0, s>>>(p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_chain(const ChainProgram &p, int batch, bool has_pow, int max_blocks, hipStream_t s)
+{
+    if (batch < 1 || batch > KC_CHAIN_MAX_BATCH || p.n_ops > KC_CHAIN_MAX_OPS) return hipErrorInvalidValue;
+    const uint64_t total = (uint64_t)p.rows * p.row_units;
+    if (total == 0) return hipSuccess;
+    if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (has_pow) {
+        constexpr int U = 1;
+        uint64_t blocks = (total + 256 * U - 1) / (256 * U);
+        if (blocks > (uint64_t)max_blocks) blocks = max_blocks;
+        return launch_chain_k<U, true>(p, dim3((unsigned)blocks, batch, 1), s);
+    }
+    constexpr int U = 2;
+    uint64_t blocks = (total + 256 * U - 1) / (256 * U);
+    if (blocks > (uint64_t)max_blocks) blocks = max_blocks;
+    return launch_chain_k<U, false>(p, dim3((unsigned)blocks, batch, 1), s);
+}
+
+// vec![v; n] (src/slot_image.rs:28-64): only when a constant plane must really exist in HBM.
+__global__ __launch_bounds__(256) void fill_kernel(float4 *dst, uint32_t pitch4, uint32_t row_units, uint32_t rows,
+                                                   float v)
+{
+    const uint32_t total = rows * row_units;
+    const float4 val = splat4(v);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const uint32_t row = idx / row_units;
+        const uint32_t col = idx - row * row_units;
+        dst[row * pitch4 + col] = val;
+    }
+}
+
+hipError_t launch_fill(float *dst, uint32_t pitch_floats, uint32_t w, uint32_t h, float v, hipStream_t s)
+{
+    const uint32_t row_units = (w + 3) / 4;
+    const uint64_t total = (uint64_t)row_units * h;
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    fill_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(reinterpret_cast<float4 *>(dst), pitch_floats / 4, row_units, h,
+                                                        v);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Separable resample = image::imageops::resize (crate image 0.24.0) as called from
+// src/shared.rs:159-199.  Weights come from host-built tap tables (resize.cpp) so they are the
+// same f32 values the scalar algorithm computes; the sums run sequentially from 0.0, unfused.
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float clamp01_nan_passthrough(float t)
+{
+    // image::math::utils::clamp: NaN compares false both ways and passes through.
+    if (t < 0.0f) return 0.0f;
+    if (t > 1.0f) return 1.0f;
+    return t;
+}
+
+// Pass 1 of the two-pass form: tmp[oy][x] = sum_j src[left_v[oy] + j][x] * w_v[oy][j].
+__global__ __launch_bounds__(256) void resize_vertical_kernel(const float *__restrict__ src, uint32_t spitch,
+                                                              uint32_t sw, float *__restrict__ tmp, uint32_t tpitch,
+                                                              TapsDev V)
+{
+    const uint32_t oy = blockIdx.y;
+    const uint32_t left = V.left[oy];
+    const uint32_t n = V.count[oy];
+    const float *w = V.w + (size_t)oy * V.stride;
+    for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < sw; x += gridDim.x * 256u) {
+        float t = 0.0f;
+        for (uint32_t j = 0; j < n; ++j) t += src[(size_t)(left + j) * spitch + x] * w[j];
+        tmp[(size_t)oy * tpitch + x] = t;
+    }
+}
+
+// Pass 2: dst[oy][ox] = clamp(sum_j tmp[oy][left_h[ox] + j] * w_h[ox][j], 0, 1).
+__global__ __launch_bounds__(256) void resize_horizontal_kernel(const float *__restrict__ tmp, uint32_t tpitch,
+                                                                float *__restrict__ dst, uint32_t dpitch,
+                                                                uint32_t dw, TapsDev H)
+{
+    const uint32_t oy = blockIdx.y;
+    for (uint32_t ox = blockIdx.x * 256u + threadIdx.x; ox < dw; ox += gridDim.x * 256u) {
+        const uint32_t left = H.left[ox];
+        const uint32_t n = H.count[ox];
+        const float *w = H.w + (size_t)ox * H.stride;
+        float t = 0.0f;
+        for (uint32_t j = 0; j < n; ++j) t += tmp[(size_t)oy * tpitch + left + j] * w[j];
+        dst[(size_t)oy * dpitch + ox] = clamp01_nan_passthrough(t);
+    }
+}
+
+hipError_t launch_resize_vertical(const float *src, uint32_t spitch, uint32_t sw, float *tmp, uint32_t tpitch,
+                                  uint32_t dh, TapsDev v, hipStream_t s)
+{
+    if (sw == 0 || dh == 0) return hipSuccess;
+    uint32_t bx = (sw + 255) / 256;
+    if (bx > 64) bx = 64;
+    resize_vertical_kernel<<<dim3(bx, dh), 256, 0, s>>>(src, spitch, sw, tmp, tpitch, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *dst, uint32_t dpitch, uint32_t dw,
+                                    uint32_t dh, TapsDev h, hipStream_t s)
+{
+    if (dw == 0 || dh == 0) return hipSuccess;
+    uint32_t bx = (dw + 255) / 256;
+    if (bx > 64) bx = 64;
+    resize_horizontal_kernel<<<dim3(bx, dh), 256, 0, s>>>(tmp, tpitch, dst, dpitch, dw, h);
+    return hipGetLastError();
+}
+
+// Single-pass LDS-tiled form: each workgroup owns a tile_h x tile_w output tile, builds the
+// vertical-pass intermediate for exactly the source columns the tile needs in LDS
+// (tile_h x ncap floats) and runs the horizontal pass out of LDS.  The intermediate never
+// touches HBM: algorithmic bytes per output pixel = 4 * (1 + in_px / out_px).
+__global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict__ src, uint32_t spitch,
+                                                         float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
+                                                         uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
+                                                         uint32_t tile_h, uint32_t ncap)
+{
+    extern __shared__ __attribute__((aligned(16))) float tmp[];
+    const uint32_t x0 = blockIdx.x * tile_w;
+    const uint32_t y0 = blockIdx.y * tile_h;
+    const uint32_t x1 = min(x0 + tile_w, dw);
+    const uint32_t y1 = min(y0 + tile_h, dh);
+    const uint32_t tw = x1 - x0;
+    const uint32_t th = y1 - y0;
+    const uint32_t c0 = H.left[x0];
+    const uint32_t c1 = H.left[x1 - 1] + H.count[x1 - 1];
+    const uint32_t nc = c1 - c0;  // <= ncap (host-checked)
+
+    for (uint32_t i = threadIdx.x; i < th * nc; i += 256u) {
+        const uint32_t ty = i / nc;
+        const uint32_t cc = i - ty * nc;
+        const uint32_t oy = y0 + ty;
+        const uint32_t left = V.left[oy];
+        const uint32_t n = V.count[oy];
+        const float *w = V.w + (size_t)oy * V.stride;
+        float t = 0.0f;
+        for (uint32_t j = 0; j < n; ++j) t += src[(size_t)(left + j) * spitch + c0 + cc] * w[j];
+        tmp[ty * ncap + cc] = t;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < th * tw; i += 256u) {
+        const uint32_t ty = i / tw;
+        const uint32_t tx = i - ty * tw;
+        const uint32_t ox = x0 + tx;
+        const uint32_t left = H.left[ox] - c0;
+        const uint32_t n = H.count[ox];
+        const float *w = H.w + (size_t)ox * H.stride;
+        const float *row = tmp + ty * ncap + left;
+        float t = 0.0f;
+        for (uint32_t j = 0; j < n; ++j) t += row[j] * w[j];
+        dst[(size_t)(y0 + ty) * dpitch + ox] = clamp01_nan_passthrough(t);
+    }
+}
+
+hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
+                             uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncap,
+                             hipStream_t s)
+{
+    if (dw == 0 || dh == 0) return hipSuccess;
+    const size_t lds = (size_t)tile_h * ncap * sizeof(float);
+    dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h);
+    resize_lds_kernel<<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncap);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// HeightToNormal: src/node/height_to_normal.rs:16-77 with the toroidal wrap of
+// src/node/process_shared.rs:31-65; nalgebra 0.29 normalize = v / sqrt((x*x + y*y) + z*z).
+// 4 B read + 12 B written per pixel (alpha is a constant plane).
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void vnorm3(float x, float y, float z, float &ox, float &oy, float &oz)
+{
+    const float n = sqrtf((x * x + y * y) + z * z);
+    ox = x / n;
+    oy = y / n;
+    oz = z / n;
+}
+
+static __device__ __forceinline__ void h2n_px(float px, float up, float left, float pdx, float pdy, float &r, float &g,
+                                              float &b)
+{
+    float tx, ty, tz, bx, by, bz, nx, ny, nz;
+    vnorm3(pdx, 0.0f, px - left, tx, ty, tz);
+    vnorm3(0.0f, pdy, up - px, bx, by, bz);
+    const float cx = ty * bz - tz * by;
+    const float cy = tz * bx - tx * bz;
+    const float cz = tx * by - ty * bx;
+    vnorm3(cx, cy, cz, nx, ny, nz);
+    r = nx * 0.5f + 0.5f;
+    g = ny * 0.5f + 0.5f;
+    b = nz * 0.5f + 0.5f;
+}
+
+__global__ __launch_bounds__(256) void height_to_normal_kernel(const float *__restrict__ hgt, uint32_t hpitch,
+                                                               uint32_t w, uint32_t h, float *__restrict__ nx,
+                                                               float *__restrict__ ny, float *__restrict__ nz,
+                                                               uint32_t opitch)
+{
+    const uint32_t row_units = (w + 3) / 4;
+    const uint32_t total = row_units * h;
+    const float pdx = 1.0f / (float)w;
+    const float pdy = 1.0f / (float)h;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const uint32_t y = idx / row_units;
+        const uint32_t q = idx - y * row_units;
+        const uint32_t yu = y == 0 ? h - 1 : y - 1;
+        const float *rowp = hgt + (size_t)y * hpitch;
+        const float4 cur = *reinterpret_cast<const float4 *>(rowp + 4 * q);
+        const float4 upv = *reinterpret_cast<const float4 *>(hgt + (size_t)yu * hpitch + 4 * q);
+        const float lft = q == 0 ? rowp[w - 1] : rowp[4 * q - 1];
+        float4 r, g, b;
+        h2n_px(cur.x, upv.x, lft, pdx, pdy, r.x, g.x, b.x);
+        h2n_px(cur.y, upv.y, cur.x, pdx, pdy, r.y, g.y, b.y);
+        h2n_px(cur.z, upv.z, cur.y, pdx, pdy, r.z, g.z, b.z);
+        h2n_px(cur.w, upv.w, cur.z, pdx, pdy, r.w, g.w, b.w);
+        const size_t o = (size_t)y * opitch + 4 * q;
+        *reinterpret_cast<float4 *>(nx + o) = r;
+        *reinterpret_cast<float4 *>(ny + o) = g;
+        *reinterpret_cast<float4 *>(nz + o) = b;
+    }
+}
+
+hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, float *nx, float *ny,
+                                   float *nz, uint32_t opitch, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)((w + 3) / 4) * h;
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    height_to_normal_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, nx, ny, nz, opitch);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// u8 boundary.  to_u8 / to_u8_srgb: src/slot_image.rs:141-207, srgb_to_linear:
+// src/slot_data.rs:100-109.  ((v.clamp(0,1) * 255.).min(255.)) as u8: truncation, NaN -> 255.
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ uint32_t quant_u8(float v)
+{
+    float x = v;
+    if (x < 0.0f) x = 0.0f;
+    if (x > 1.0f) x = 1.0f;  // NaN falls through both
+    x = x * 255.0f;
+    if (!(x <= 255.0f)) x = 255.0f;  // f32::min(255.): NaN -> 255
+    return (uint32_t)x;               // 0 <= x <= 255: truncation
+}
+
+static __device__ __forceinline__ float srgb_to_linear(float s)
+{
+    if (s <= 0.0f) return s;
+    if (s <= 0.04045f) return s / 12.92f;
+    return kc_powf((s + 0.055f) / 1.055f, 2.4f);
+}
+
+static __device__ __forceinline__ uint32_t quant_u8_srgb(float v)
+{
+    float x = v;
+    if (x < 0.0f) x = 0.0f;
+    if (x > 1.0f) x = 1.0f;
+    x = srgb_to_linear(x) * 255.0f;
+    if (!(x <= 255.0f)) x = 255.0f;
+    return (uint32_t)x;
+}
+
+static __device__ __forceinline__ float4 load_operand4(const Operand &o, uint32_t row, uint32_t q)
+{
+    if (o.ptr == nullptr) return splat4(o.c);
+    return *reinterpret_cast<const float4 *>(o.ptr + (size_t)row * o.pitch + 4 * q);
+}
+
+template <bool SRGB>
+__global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operand b, Operand a, int gray, uint32_t w,
+                                                    uint32_t h, uint8_t *__restrict__ dst)
+{
+    const uint32_t row_units = (w + 3) / 4;
+    const uint32_t total = row_units * h;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const uint32_t y = idx / row_units;
+        const uint32_t q = idx - y * row_units;
+        const float4 vr = load_operand4(r, y, q);
+        float rr[4] = { vr.x, vr.y, vr.z, vr.w };
+        uint32_t px[4];
+        if (gray) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t v = SRGB ? quant_u8_srgb(rr[e]) : quant_u8(rr[e]);
+                px[e] = v | (v << 8) | (v << 16) | (255u << 24);
+            }
+        } else {
+            const float4 vg = load_operand4(g, y, q);
+            const float4 vb = load_operand4(b, y, q);
+            const float4 va = load_operand4(a, y, q);
+            float gg[4] = { vg.x, vg.y, vg.z, vg.w };
+            float bb[4] = { vb.x, vb.y, vb.z, vb.w };
+            float aa[4] = { va.x, va.y, va.z, va.w };
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t qr = SRGB ? quant_u8_srgb(rr[e]) : quant_u8(rr[e]);
+                const uint32_t qg = SRGB ? quant_u8_srgb(gg[e]) : quant_u8(gg[e]);
+                const uint32_t qb = SRGB ? quant_u8_srgb(bb[e]) : quant_u8(bb[e]);
+                const uint32_t qa = quant_u8(aa[e]);
+                px[e] = qr | (qg << 8) | (qb << 16) | (qa << 24);
+            }
+        }
+        uint32_t *o = reinterpret_cast<uint32_t *>(dst) + (size_t)y * w + 4 * q;
+        if (4 * q + 3 < w && (w & 3u) == 0) {
+            *reinterpret_cast<uint4 *>(o) = make_uint4(px[0], px[1], px[2], px[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < w) o[e] = px[e];
+        }
+    }
+}
+
+hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,
+                        uint8_t *dst, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)((w + 3) / 4) * h;
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (srgb)
+        to_u8_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
+    else
+        to_u8_kernel<false><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
+    return hipGetLastError();
+}
+
+// deconstruct_image, src/shared.rs:16-56: interleaved u8 (1..4 channels) -> planar f32 / 255.;
+// channels the file lacks become constant planes on the host side (R,G,B = 0, A = 1).
+__global__ __launch_bounds__(256) void from_u8_kernel(const uint8_t *__restrict__ src, int channels, uint32_t w,
+                                                      uint32_t h, float *p0, float *p1, float *p2, float *p3,
+                                                      uint32_t pitch)
+{
+    const uint32_t total = w * h;
+    float *planes[4] = { p0, p1, p2, p3 };
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const uint32_t y = idx / w;
+        const uint32_t x = idx - y * w;
+        if (channels == 4) {
+            const uint32_t v = reinterpret_cast<const uint32_t *>(src)[idx];
+            p0[(size_t)y * pitch + x] = (float)(v & 255u) / 255.0f;
+            p1[(size_t)y * pitch + x] = (float)((v >> 8) & 255u) / 255.0f;
+            p2[(size_t)y * pitch + x] = (float)((v >> 16) & 255u) / 255.0f;
+            p3[(size_t)y * pitch + x] = (float)(v >> 24) / 255.0f;
+        } else {
+            for (int c = 0; c < channels; ++c)
+                planes[c][(size_t)y * pitch + x] = (float)src[(size_t)idx * channels + c] / 255.0f;
+        }
+    }
+}
+
+hipError_t launch_from_u8(const uint8_t *src, int channels, uint32_t w, uint32_t h, float *const planes[4],
+                          uint32_t pitch, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)w * h;
+    if (total == 0) return hipSuccess;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    from_u8_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(src, channels, w, h, planes[0], planes[1], planes[2],
+                                                          planes[3], pitch);
+    return hipGetLastError();
+}
+
+}  // namespace kc

@@ -1,0 +1,238 @@
+// Implicit input resize: resize_buffers (src/shared.rs:141-216) -> image::imageops::resize.
+// The resampler's arithmetic lives in crate `image` 0.24.0 (imageops/sample.rs), which is not
+// vendored with the reference; this file follows that crate's published algorithm:
+// per axis, for output index o:  ratio = in/out (f32), sratio = max(ratio, 1), S = support*sratio,
+// c = (o + 0.5)*ratio, left = clamp(floor(c - S), 0, in-1), right = clamp(ceil(c + S), left+1, in),
+// w_i = K((i - (c - 0.5)) / sratio), normalised by their sequential f32 sum.  The tap tables are
+// built here on the host with the same libm calls (sinf / expf) Rust's f32::sin / f32::exp
+// lower to, uploaded once per (in, out, filter) and cached; the kernels only multiply-add.
+#include <cmath>
+#include <cstdlib>
+
+#include "kc_runtime.hpp"
+
+namespace kc {
+
+static float k_box(float) { return 1.0f; }
+
+static float k_triangle(float x)
+{
+    const float a = std::fabs(x);
+    return a < 1.0f ? 1.0f - a : 0.0f;
+}
+
+static float k_catmullrom(float x)
+{
+    // Mitchell-Netravali BC-spline with b = 0, c = 0.5; a.powi(3) = (a*a)*a, a.powi(2) = a*a
+    const float b = 0.0f, c = 0.5f;
+    const float a = std::fabs(x);
+    float k = 0.0f;
+    if (a < 1.0f)
+        k = (12.0f - 9.0f * b - 6.0f * c) * ((a * a) * a) + (-18.0f + 12.0f * b + 6.0f * c) * (a * a) + (6.0f - 2.0f * b);
+    else if (a < 2.0f)
+        k = (-b - 6.0f * c) * ((a * a) * a) + (6.0f * b + 30.0f * c) * (a * a) + (-12.0f * b - 48.0f * c) * a +
+            (8.0f * b + 24.0f * c);
+    return k / 6.0f;
+}
+
+static float k_gaussian(float x)
+{
+    const float r = 0.5f;
+    const float pi = 3.14159265358979323846f;
+    return (1.0f / (std::sqrt(2.0f * pi) * r)) * std::exp(-(x * x) / (2.0f * (r * r)));
+}
+
+static float sinc(float t)
+{
+    const float a = t * 3.14159265358979323846f;
+    return t == 0.0f ? 1.0f : std::sin(a) / a;
+}
+
+static float k_lanczos3(float x) { return std::fabs(x) < 3.0f ? sinc(x) * sinc(x / 3.0f) : 0.0f; }
+
+int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
+{
+    float (*kern)(float) = nullptr;
+    float support = 0.0f;
+    switch (filter) {
+    case KC_FILTER_NEAREST: kern = k_box; support = 0.0f; break;
+    case KC_FILTER_TRIANGLE: kern = k_triangle; support = 1.0f; break;
+    case KC_FILTER_CATMULLROM: kern = k_catmullrom; support = 2.0f; break;
+    case KC_FILTER_GAUSSIAN: kern = k_gaussian; support = 3.0f; break;
+    case KC_FILTER_LANCZOS3: kern = k_lanczos3; support = 3.0f; break;
+    default: set_error("invalid ResizeFilter"); return KC_ERR_INVALID_ARG;
+    }
+    if (in_n == 0 || out_n == 0) {
+        set_error("resize with zero extent");
+        return KC_ERR_INVALID_ARG;
+    }
+    const float ratio = (float)in_n / (float)out_n;
+    const float sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float src_support = support * sratio;
+    t.left.resize(out_n);
+    t.count.resize(out_n);
+    t.stride = 1;
+    for (uint32_t o = 0; o < out_n; ++o) {
+        const float input = ((float)o + 0.5f) * ratio;
+        int64_t l = (int64_t)std::floor(input - src_support);
+        if (l < 0) l = 0;
+        if (l > (int64_t)in_n - 1) l = (int64_t)in_n - 1;
+        int64_t r = (int64_t)std::ceil(input + src_support);
+        if (r < l + 1) r = l + 1;
+        if (r > (int64_t)in_n) r = (int64_t)in_n;
+        t.left[o] = (uint32_t)l;
+        t.count[o] = (uint32_t)(r - l);
+        if (t.count[o] > t.stride) t.stride = t.count[o];
+    }
+    t.w.assign((size_t)out_n * t.stride, 0.0f);
+    for (uint32_t o = 0; o < out_n; ++o) {
+        const float input = ((float)o + 0.5f) * ratio - 0.5f;
+        float *w = &t.w[(size_t)o * t.stride];
+        float sum = 0.0f;
+        for (uint32_t j = 0; j < t.count[o]; ++j) {
+            w[j] = kern(((float)(t.left[o] + j) - input) / sratio);
+            sum += w[j];
+        }
+        for (uint32_t j = 0; j < t.count[o]; ++j) w[j] /= sum;
+    }
+    return KC_OK;
+}
+
+static int get_taps(uint32_t in_n, uint32_t out_n, int filter, TapsEntry **out)
+{
+    Context &c = ctx();
+    auto key = std::make_tuple(in_n, out_n, filter);
+    auto it = c.taps.find(key);
+    if (it != c.taps.end()) {
+        *out = &it->second;
+        return KC_OK;
+    }
+    TapsEntry e;
+    KC_TRY(build_taps_host(in_n, out_n, filter, e.host));
+    const size_t nl = (size_t)out_n * sizeof(uint32_t);
+    const size_t nw = e.host.w.size() * sizeof(float);
+    const size_t nl_pad = (nl + 255) / 256 * 256;
+    e.dev_bytes = 2 * nl_pad + (nw + 255) / 256 * 256;
+    KC_HIP(hipMalloc(&e.dev_block, e.dev_bytes));
+    char *base = (char *)e.dev_block;
+    hipError_t err = hipMemcpyAsync(base, e.host.left.data(), nl, hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(base + nl_pad, e.host.count.data(), nl, hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(base + 2 * nl_pad, e.host.w.data(), nw, hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
+    if (err != hipSuccess) {
+        (void)hipFree(e.dev_block);
+        return hip_fail(err, "upload tap table");
+    }
+    e.dev.left = (const uint32_t *)base;
+    e.dev.count = (const uint32_t *)(base + nl_pad);
+    e.dev.w = (const float *)(base + 2 * nl_pad);
+    e.dev.stride = e.host.stride;
+    auto ins = c.taps.emplace(key, std::move(e));
+    *out = &ins.first->second;
+    return KC_OK;
+}
+
+// Widest source-column window any tile_w-wide output tile needs.
+static uint32_t tile_ncap(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
+{
+    uint32_t cap = 1;
+    for (uint32_t x0 = 0; x0 < out_n; x0 += tile_w) {
+        const uint32_t x1 = std::min(out_n, x0 + tile_w);
+        const uint32_t n = h.left[x1 - 1] + h.count[x1 - 1] - h.left[x0];
+        if (n > cap) cap = n;
+    }
+    return cap;
+}
+
+static int resize_plane(kc_plane *src, kc_size size, int filter, kc_plane **out)
+{
+    Context &c = ctx();
+    // A 1x1 source has a single tap whose normalised weight is w/w = 1, in both passes:
+    // t = 0.0 + v*1.0 (vertical), u = 0.0 + t*1.0 then clamp (horizontal) -- a constant plane.
+    if (src->w == 1 && src->h == 1 && src->kind == kc_plane::CONST) {
+        float t = 0.0f;
+        t += src->cval * 1.0f;
+        float u = 0.0f;
+        u += t * 1.0f;
+        if (u < 0.0f) u = 0.0f;
+        else if (u > 1.0f) u = 1.0f;
+        *out = plane_new_const(size.width, size.height, u);
+        return KC_OK;
+    }
+    KC_TRY(need_init());
+    KC_TRY(plane_materialize(src));
+    TapsEntry *tv = nullptr, *th = nullptr;
+    KC_TRY(get_taps(src->h, size.height, filter, &tv));
+    KC_TRY(get_taps(src->w, size.width, filter, &th));
+    kc_plane *dst = nullptr;
+    KC_TRY(plane_new_mem(size.width, size.height, &dst));
+    const uint32_t spitch = (uint32_t)(src->pitch / 4), dpitch = (uint32_t)(dst->pitch / 4);
+
+    // LDS-tiled single pass when the vertical-pass intermediate of one tile fits in 64 KiB of
+    // LDS; otherwise (very large down-sampling windows) two passes through an HBM intermediate.
+    static const uint32_t tiles[][2] = { { 128, 16 }, { 64, 16 }, { 64, 8 }, { 32, 8 }, { 16, 8 }, { 16, 4 } };
+    bool done = false;
+    if (!c.resize_two_pass) {
+        for (auto &tl : tiles) {
+            const uint32_t ncap = tile_ncap(th->host, size.width, tl[0]);
+            if ((size_t)tl[1] * ncap * sizeof(float) <= 64 * 1024) {
+                hipError_t e = launch_resize_lds(src->dptr, spitch, dst->dptr, dpitch, size.width, size.height, tv->dev,
+                                                 th->dev, tl[0], tl[1], ncap, c.stream);
+                if (e != hipSuccess) {
+                    plane_release(dst);
+                    return hip_fail(e, "launch_resize_lds");
+                }
+                c.launches++;
+                done = true;
+                break;
+            }
+        }
+    }
+    if (!done) {
+        kc_plane *tmp = nullptr;
+        int s = plane_new_mem(src->w, size.height, &tmp);
+        if (s != KC_OK) {
+            plane_release(dst);
+            return s;
+        }
+        const uint32_t tpitch = (uint32_t)(tmp->pitch / 4);
+        hipError_t e = launch_resize_vertical(src->dptr, spitch, src->w, tmp->dptr, tpitch, size.height, tv->dev, c.stream);
+        if (e == hipSuccess)
+            e = launch_resize_horizontal(tmp->dptr, tpitch, dst->dptr, dpitch, size.width, size.height, th->dev, c.stream);
+        plane_release(tmp);
+        if (e != hipSuccess) {
+            plane_release(dst);
+            return hip_fail(e, "launch_resize two-pass");
+        }
+        c.launches += 2;
+    }
+    *out = dst;
+    return KC_OK;
+}
+
+// One imageops::resize call per plane, as src/shared.rs:156-201 does (1 for Gray, 4 for Rgba --
+// aliased planes, e.g. Gray->Rgba [p, p, p, ones], are resampled once and re-aliased).
+int resize_image(kc_image *src, kc_size size, int filter, kc_image **out)
+{
+    if (size.width == 0 || size.height == 0) {
+        set_error("resize to zero extent");
+        return KC_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    kc_plane *p[4] = { nullptr, nullptr, nullptr, nullptr };
+    int s = KC_OK;
+    for (int i = 0; i < src->n && s == KC_OK; ++i) {
+        for (int j = 0; j < i; ++j)
+            if (src->planes[j] == src->planes[i]) {
+                p[i] = p[j];
+                plane_retain(p[i]);
+                break;
+            }
+        if (!p[i]) s = resize_plane(src->planes[i], size, filter, &p[i]);
+    }
+    if (s == KC_OK) *out = image_new(src->n, p);
+    for (int i = 0; i < src->n; ++i) plane_release(p[i]);
+    return s;
+}
+
+}  // namespace kc

@@ -1,0 +1,474 @@
+// Context, HBM plane pool, planes, images and the lazy pointwise-chain machinery.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "kc_runtime.hpp"
+
+namespace kc {
+
+static thread_local std::string g_last_error;
+
+Context &ctx()
+{
+    static Context c;
+    return c;
+}
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+const std::string &last_error() { return g_last_error; }
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return KC_ERR_HIP;
+}
+
+int need_init()
+{
+    if (!ctx().inited) {
+        set_error("kc_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)");
+        return KC_ERR_NO_DEVICE;
+    }
+    return KC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Pool: exact-size free lists.  Everything runs on one stream, so a block freed by the host can
+// be handed to the next kernel immediately (stream order makes the reuse safe).  Replaces the
+// reference's RAM/disk tiering (src/transient_buffer.rs:249-434): 288 GB of HBM hold the planes.
+// ------------------------------------------------------------------------------------------
+int pool_alloc(size_t bytes, void **out)
+{
+    Context &c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    auto it = c.free_blocks.find(bytes);
+    if (it != c.free_blocks.end()) {
+        *out = it->second;
+        c.free_blocks.erase(it);
+        c.bytes_cached -= bytes;
+        c.bytes_in_use += bytes;
+        return KC_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(out, bytes);
+    }
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        set_error("out of HBM");
+        return KC_ERR_OUT_OF_MEMORY;
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    c.bytes_in_use += bytes;
+    return KC_OK;
+}
+
+void pool_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    Context &c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    if (!c.inited) return;  // device already torn down
+    c.free_blocks.emplace(bytes, p);
+    c.bytes_in_use -= bytes;
+    c.bytes_cached += bytes;
+}
+
+int pool_trim()
+{
+    Context &c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    for (auto &kv : c.free_blocks) (void)hipFree(kv.second);
+    c.free_blocks.clear();
+    c.bytes_cached = 0;
+    return KC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Planes
+// ------------------------------------------------------------------------------------------
+static size_t pitch_for(uint32_t w)
+{
+    size_t row = (size_t)w * sizeof(float);
+    return (row + 255) / 256 * 256;
+}
+
+int plane_new_mem(uint32_t w, uint32_t h, kc_plane **out)
+{
+    KC_TRY(need_init());
+    if (w == 0 || h == 0) {
+        set_error("plane with zero extent");
+        return KC_ERR_INVALID_ARG;
+    }
+    kc_plane *p = new kc_plane();
+    p->w = w;
+    p->h = h;
+    p->kind = kc_plane::MEM;
+    p->pitch = pitch_for(w);
+    p->bytes = p->pitch * h;
+    p->owned = true;
+    void *d = nullptr;
+    int s = pool_alloc(p->bytes, &d);
+    if (s != KC_OK) {
+        delete p;
+        return s;
+    }
+    p->dptr = (float *)d;
+    *out = p;
+    return KC_OK;
+}
+
+kc_plane *plane_new_const(uint32_t w, uint32_t h, float v)
+{
+    kc_plane *p = new kc_plane();
+    p->w = w;
+    p->h = h;
+    p->kind = kc_plane::CONST;
+    p->cval = v;
+    return p;
+}
+
+void plane_retain(kc_plane *p)
+{
+    if (p) p->refs.fetch_add(1, std::memory_order_relaxed);
+}
+
+void plane_release(kc_plane *p)
+{
+    if (!p) return;
+    if (p->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        if (p->chain) delete p->chain;
+        if (p->owned && p->dptr) pool_free(p->dptr, p->bytes);
+        delete p;
+    }
+}
+
+Chain::~Chain()
+{
+    plane_release(start);
+    for (auto &s : steps) plane_release(s.operand);
+}
+
+Operand plane_operand(const kc_plane *p)
+{
+    Operand o;
+    if (p->kind == kc_plane::CONST) {
+        o.ptr = nullptr;
+        o.pitch = 0;
+        o.c = p->cval;
+    } else {
+        o.ptr = p->dptr;
+        o.pitch = (uint32_t)(p->pitch / sizeof(float));
+        o.c = 0.0f;
+    }
+    return o;
+}
+
+// ---- building the kernel program for one lazy plane -------------------------------------
+struct BuiltChain {
+    std::vector<const kc_plane *> inputs;  // distinct MEM planes, index = kernel input slot
+    ChainProgram prog;
+    bool has_pow = false;
+};
+
+static int input_index(std::vector<const kc_plane *> &ins, const kc_plane *p)
+{
+    for (size_t i = 0; i < ins.size(); ++i)
+        if (ins[i]->dptr == p->dptr && ins[i]->pitch == p->pitch) return (int)i;
+    ins.push_back(p);
+    return (int)ins.size() - 1;
+}
+
+// Fills entry `b` of the program from plane `p`'s chain.  When b > 0 the codes / operand
+// pattern must equal entry 0's (returns false otherwise).
+static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
+{
+    const Chain &ch = *p->chain;
+    ChainProgram &P = bc.prog;
+    std::vector<const kc_plane *> ins;
+    int start_src = -1;
+    if (ch.start->kind == kc_plane::MEM) start_src = input_index(ins, ch.start);
+    if (b == 0) {
+        std::memset(&P, 0, sizeof(P));
+        P.n_ops = (uint32_t)ch.steps.size();
+        P.start_src = start_src;
+    } else if (P.n_ops != ch.steps.size() || P.start_src != start_src) {
+        return false;
+    }
+    P.start_c[b] = ch.start->kind == kc_plane::CONST ? ch.start->cval : 0.0f;
+    for (size_t i = 0; i < ch.steps.size(); ++i) {
+        const ChainStep &st = ch.steps[i];
+        int src = -1;
+        float c = 0.0f;
+        if (st.operand->kind == kc_plane::MEM)
+            src = input_index(ins, st.operand);
+        else
+            c = st.operand->cval;
+        if (b == 0) {
+            P.code[i] = st.code;
+            P.src[i] = (int8_t)src;
+            if (st.code == CH_POW_L || st.code == CH_POW_R) bc.has_pow = true;
+        } else if (P.code[i] != st.code || P.src[i] != (int8_t)src) {
+            return false;
+        }
+        P.c[b][i] = c;
+    }
+    if (b == 0)
+        P.n_in = (uint32_t)ins.size();
+    else if (P.n_in != ins.size())
+        return false;
+    for (size_t k = 0; k < ins.size(); ++k) {
+        P.in[b][k] = ins[k]->dptr;
+        P.in_pitch[b][k] = (uint32_t)(ins[k]->pitch / 16);
+    }
+    return true;
+}
+
+static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
+{
+    Context &c = ctx();
+    ChainProgram &P = bc.prog;
+    const kc_plane *p0 = planes[0];
+    const uint32_t row_units = (p0->w + 3) / 4;
+    // Outputs are fresh pool planes, all with the pitch of their width.
+    std::vector<kc_plane *> outs(batch, nullptr);
+    for (int b = 0; b < batch; ++b) {
+        int s = plane_new_mem(p0->w, p0->h, &outs[b]);
+        if (s != KC_OK) {
+            for (auto *o : outs) plane_release(o);
+            return s;
+        }
+        P.out[b] = outs[b]->dptr;
+        P.out_pitch[b] = (uint32_t)(outs[b]->pitch / 16);
+    }
+    // Rows can be flattened into one run when every plane is dense (pitch == 16 * row_units).
+    bool dense = (size_t)row_units * 16 == outs[0]->pitch;
+    for (int b = 0; b < batch && dense; ++b)
+        for (uint32_t k = 0; k < P.n_in; ++k)
+            if (P.in_pitch[b][k] != row_units) dense = false;
+    if (dense) {
+        P.rows = 1;
+        P.row_units = row_units * p0->h;
+    } else {
+        P.rows = p0->h;
+        P.row_units = row_units;
+    }
+    hipError_t e = launch_chain(P, batch, bc.has_pow, c.max_blocks, c.stream);
+    if (e != hipSuccess) {
+        for (auto *o : outs) plane_release(o);
+        return hip_fail(e, "launch_chain");
+    }
+    c.launches++;
+    for (int b = 0; b < batch; ++b) {
+        kc_plane *p = planes[b];
+        Chain *old = p->chain;
+        p->chain = nullptr;
+        p->kind = kc_plane::MEM;
+        p->dptr = outs[b]->dptr;
+        p->pitch = outs[b]->pitch;
+        p->bytes = outs[b]->bytes;
+        p->owned = true;
+        outs[b]->owned = false;  // ownership of the block moved into p
+        outs[b]->dptr = nullptr;
+        plane_release(outs[b]);
+        delete old;  // drops the operand references (after the launch is enqueued)
+    }
+    return KC_OK;
+}
+
+int planes_force(kc_plane *const *planes, int n)
+{
+    KC_TRY(need_init());
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    std::vector<kc_plane *> todo;
+    for (int i = 0; i < n; ++i) {
+        kc_plane *p = planes[i];
+        if (!p || p->kind != kc_plane::LAZY) continue;
+        bool dup = false;
+        for (auto *q : todo) dup |= (q == p);
+        if (!dup) todo.push_back(p);
+    }
+    size_t i = 0;
+    while (i < todo.size()) {
+        BuiltChain bc;
+        kc_plane *group[KC_CHAIN_MAX_BATCH];
+        int batch = 0;
+        chain_fill(bc, 0, todo[i]);
+        group[batch++] = todo[i];
+        size_t j = i + 1;
+        while (j < todo.size() && batch < KC_CHAIN_MAX_BATCH && todo[j]->w == todo[i]->w &&
+               todo[j]->h == todo[i]->h && chain_fill(bc, batch, todo[j])) {
+            group[batch++] = todo[j];
+            ++j;
+        }
+        KC_TRY(chain_launch(bc, group, batch));
+        i = j;
+    }
+    return KC_OK;
+}
+
+int plane_force(kc_plane *p) { return planes_force(&p, 1); }
+
+int plane_materialize(kc_plane *p)
+{
+    KC_TRY(need_init());
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    if (p->kind == kc_plane::LAZY) return plane_force(p);
+    if (p->kind == kc_plane::CONST) {
+        kc_plane *m = nullptr;
+        KC_TRY(plane_new_mem(p->w, p->h, &m));
+        hipError_t e = launch_fill(m->dptr, (uint32_t)(m->pitch / 4), p->w, p->h, p->cval, ctx().stream);
+        if (e != hipSuccess) {
+            plane_release(m);
+            return hip_fail(e, "launch_fill");
+        }
+        ctx().launches++;
+        p->kind = kc_plane::MEM;
+        p->dptr = m->dptr;
+        p->pitch = m->pitch;
+        p->bytes = m->bytes;
+        p->owned = true;
+        m->owned = false;
+        m->dptr = nullptr;
+        plane_release(m);
+    }
+    return KC_OK;
+}
+
+// ---- l op r ------------------------------------------------------------------------------
+static float fold_const(int mix, float l, float r)
+{
+    switch (mix) {
+    case KC_MIX_ADD: return l + r;
+    case KC_MIX_SUBTRACT: return l - r;
+    case KC_MIX_MULTIPLY: return l * r;
+    case KC_MIX_DIVIDE: return l / r;
+    default: return (float)std::pow((double)l, (double)r);  // same f64-then-round rule as the kernel
+    }
+}
+
+static uint8_t code_for(int mix, bool acc_is_left)
+{
+    switch (mix) {
+    case KC_MIX_ADD: return acc_is_left ? CH_ADD : CH_ADD_R;
+    case KC_MIX_SUBTRACT: return acc_is_left ? CH_SUB_L : CH_SUB_R;
+    case KC_MIX_MULTIPLY: return acc_is_left ? CH_MUL : CH_MUL_R;
+    case KC_MIX_DIVIDE: return acc_is_left ? CH_DIV_L : CH_DIV_R;
+    default: return acc_is_left ? CH_POW_L : CH_POW_R;
+    }
+}
+
+static int chain_distinct_inputs(const Chain &ch, const kc_plane *extra)
+{
+    std::vector<const kc_plane *> ins;
+    if (ch.start->kind == kc_plane::MEM) input_index(ins, ch.start);
+    for (auto &s : ch.steps)
+        if (s.operand->kind == kc_plane::MEM) input_index(ins, s.operand);
+    if (extra && extra->kind == kc_plane::MEM) input_index(ins, extra);
+    return (int)ins.size();
+}
+
+int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
+{
+    if (mix < KC_MIX_ADD || mix > KC_MIX_POW) {
+        set_error("invalid MixType");
+        return KC_ERR_INVALID_ARG;
+    }
+    if (l->w != r->w || l->h != r->h) {
+        set_error("Mix operands differ in size (resize_buffers must run first)");
+        return KC_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    if (l->kind == kc_plane::CONST && r->kind == kc_plane::CONST) {
+        *out = plane_new_const(l->w, l->h, fold_const(mix, l->cval, r->cval));
+        return KC_OK;
+    }
+    KC_TRY(need_init());
+    // Pick the running value: a lazy operand is continued, the other side becomes the step operand.
+    kc_plane *acc = nullptr, *opnd = nullptr;
+    bool acc_is_left = true;
+    if (l->kind == kc_plane::LAZY && r->kind == kc_plane::LAZY) {
+        // keep the longer chain lazy, run the shorter one now
+        if (l != r && l->chain->steps.size() >= r->chain->steps.size())
+            KC_TRY(plane_force(r));
+        else
+            KC_TRY(plane_force(l));
+    }
+    if (l->kind == kc_plane::LAZY) {
+        acc = l;
+        opnd = r;
+        acc_is_left = true;
+    } else if (r->kind == kc_plane::LAZY) {
+        acc = r;
+        opnd = l;
+        acc_is_left = false;
+    }
+    kc_plane *res = new kc_plane();
+    res->w = l->w;
+    res->h = l->h;
+    res->kind = kc_plane::LAZY;
+    res->chain = new Chain();
+    if (acc) {
+        // A chain that is full (steps or distinct inputs) is run first and restarted from its result.
+        if (acc->chain->steps.size() >= (size_t)KC_CHAIN_MAX_OPS ||
+            chain_distinct_inputs(*acc->chain, opnd) > KC_CHAIN_MAX_IN) {
+            int s = plane_force(acc);
+            if (s != KC_OK) {
+                plane_release(res);
+                return s;
+            }
+            acc = nullptr;
+        }
+    }
+    if (acc) {
+        res->chain->start = acc->chain->start;
+        plane_retain(res->chain->start);
+        res->chain->steps = acc->chain->steps;
+        for (auto &s : res->chain->steps) plane_retain(s.operand);
+        res->chain->steps.push_back({ code_for(mix, acc_is_left), opnd });
+        plane_retain(opnd);
+    } else {
+        res->chain->start = l;
+        plane_retain(l);
+        res->chain->steps.push_back({ code_for(mix, true), r });
+        plane_retain(r);
+    }
+    *out = res;
+    return KC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Images
+// ------------------------------------------------------------------------------------------
+kc_image *image_new(int n, kc_plane *const *planes)
+{
+    kc_image *img = new kc_image();
+    img->n = n;
+    for (int i = 0; i < n; ++i) {
+        img->planes[i] = planes[i];
+        plane_retain(planes[i]);
+    }
+    return img;
+}
+
+void image_retain(kc_image *img)
+{
+    if (img) img->refs.fetch_add(1, std::memory_order_relaxed);
+}
+
+void image_release(kc_image *img)
+{
+    if (!img) return;
+    if (img->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        for (int i = 0; i < img->n; ++i) plane_release(img->planes[i]);
+        delete img;
+    }
+}
+
+int image_force(kc_image *img) { return planes_force(img->planes, img->n); }
+
+}  // namespace kc

@@ -1,0 +1,232 @@
+"""GPU parity, level 2: each HIP kernel against the CPU oracle at f32 on seeded synthetic planes
+(with IEEE edge cases spliced in), through the C ABI operator entry points."""
+import numpy as np
+import pytest
+
+from util import (SEED_A, SEED_B, assert_planes, bit_equal, max_ulp, splitmix_plane, synthetic_rgba,
+                  with_edge_cases)
+
+pytestmark = pytest.mark.gpu
+
+OPS = ["Add", "Subtract", "Multiply", "Divide", "Pow"]
+FILTERS = ["Nearest", "Triangle", "CatmullRom", "Gaussian", "Lanczos3"]
+
+
+@pytest.fixture(scope="module")
+def kc():
+    import kanter_core_amd as kc
+    kc.init(0)
+    return kc
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as orc
+    return orc
+
+
+def _ulp(op):
+    return 1 if op == "Pow" else 0
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (37, 101), (1, 1), (3, 1), (1, 7), (256, 260)])
+@pytest.mark.parametrize("op", OPS)
+def test_mix_gray(kc, orc, op, shape):
+    h, w = shape
+    a = with_edge_cases(splitmix_plane(SEED_A, 0, h, w), 1)
+    b = with_edge_cases(splitmix_plane(SEED_B, 0, h, w), 3)
+    got = kc.mix_process(kc.SlotImage.from_planes([a]), kc.SlotImage.from_planes([b]), kc.MixType.parse(op))
+    assert not got.is_rgba()
+    assert_planes(got.planes(), [orc.mix_plane(op, a, b)], ulp=_ulp(op), what=op)
+
+
+@pytest.mark.parametrize("fusion", [True, False])
+@pytest.mark.parametrize("op", OPS)
+def test_mix_rgba_alpha_is_one_and_input_alpha_ignored(kc, orc, op, fusion):
+    h, w = 96, 130
+    a = [with_edge_cases(p, 1) for p in synthetic_rgba(SEED_A, h, w)]
+    b = [with_edge_cases(p, 2) for p in synthetic_rgba(SEED_B, h, w)]
+    kc.set_fusion(fusion)
+    try:
+        got = kc.mix_process(kc.SlotImage.from_planes(a), kc.SlotImage.from_planes(b), kc.MixType.parse(op))
+        planes = got.planes()
+    finally:
+        kc.set_fusion(True)
+    want = [orc.mix_plane(op, a[c], b[c]) for c in range(3)] + [np.ones((h, w), np.float32)]
+    assert_planes(planes, want, ulp=_ulp(op), what=op)
+
+
+def test_mix_missing_inputs_and_type_matching(kc, orc):
+    h, w = 40, 48
+    a = synthetic_rgba(SEED_A, h, w)
+    g = splitmix_plane(SEED_B, 0, h, w)
+    rgba, gray = kc.SlotImage.from_planes(a), kc.SlotImage.from_planes([g])
+    # only left: right = zeros of left's type (mix.rs:64)
+    got = kc.mix_process(rgba, None, kc.MixType.Add).planes()
+    assert_planes(got, [orc.mix_plane("Add", a[c], np.zeros_like(g)) for c in range(3)] + [np.ones_like(g)])
+    # only right: left = zeros, Subtract gives 0 - r (mix.rs:69-76)
+    got = kc.mix_process(None, gray, kc.MixType.Subtract).planes()
+    assert_planes(got, [orc.mix_plane("Subtract", np.zeros_like(g), g)])
+    # neither: 1x1 gray 0.0 (mix.rs:77-83)
+    img = kc.mix_process(None, None, kc.MixType.Add)
+    assert img.size() == (1, 1) and not img.is_rgba() and img.planes()[0][0, 0] == 0.0
+    # gray left, rgba right: right averaged to gray ((r+g)+b)/3 first, output gray (mix.rs:57-62)
+    got = kc.mix_process(gray, rgba, kc.MixType.Multiply)
+    assert not got.is_rgba()
+    assert_planes(got.planes(), [orc.mix_plane("Multiply", g, orc.rgba_to_gray(*a[:3]))])
+    # rgba left, gray right: right broadcast to [p, p, p, 1]
+    got = kc.mix_process(rgba, gray, kc.MixType.Divide)
+    assert_planes(got.planes(), [orc.mix_plane("Divide", a[c], g) for c in range(3)] + [np.ones_like(g)])
+
+
+def test_as_type_and_from_value(kc, orc):
+    h, w = 33, 77
+    a = [with_edge_cases(p, 1) for p in synthetic_rgba(SEED_A, h, w)]
+    img = kc.SlotImage.from_planes(a)
+    assert_planes(img.as_type(False).planes(), [orc.rgba_to_gray(*a[:3])])
+    g = kc.SlotImage.from_planes([a[0]]).as_type(True).planes()
+    assert_planes(g, [a[0], a[0], a[0], np.ones_like(a[0])])
+    v = kc.SlotImage.from_value((5, 3), 0.25, True).planes()
+    assert [float(p[0, 0]) for p in v] == [0.25, 0.25, 0.25, 1.0] and v[0].shape == (3, 5)
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (9, 13)])
+def test_fused_chain_equals_unfused_and_oracle(kc, orc, shape):
+    """The 32-node linear graph of SURVEY.md 8(d) config #3 as direct operator calls."""
+    h, w = shape
+    a, b = synthetic_rgba(SEED_A, h, w), synthetic_rgba(SEED_B, h, w)
+    want = orc.chain32(a, b, 32)
+
+    def run():
+        x = kc.SlotImage.from_planes(a)
+        bb = kc.SlotImage.from_planes(b)
+        white = kc.combine_rgba_process([kc.value_process(1.0)] * 3 + [None])
+        for i in range(1, 33):
+            if i & 1:
+                x = kc.mix_process(x, bb, kc.MixType.Multiply if (i >> 1) & 1 else kc.MixType.Add)
+            else:
+                x = kc.mix_process(kc.resize_image(white, (w, h)), x, kc.MixType.Subtract)
+        return x.planes()
+
+    l0 = kc.stats()["kernel_launches"]
+    fused = run()
+    l1 = kc.stats()["kernel_launches"]
+    kc.set_fusion(False)
+    try:
+        unfused = run()
+    finally:
+        kc.set_fusion(True)
+    l2 = kc.stats()["kernel_launches"]
+    assert_planes(fused, want, what="fused vs oracle")
+    assert_planes(unfused, want, what="unfused vs oracle")
+    assert l1 - l0 == 1, "the whole chain must be one kernel launch"
+    assert l2 - l1 == 32
+
+
+@pytest.mark.parametrize("filt", FILTERS)
+@pytest.mark.parametrize("src,dst", [((16, 16), (128, 128)), ((110, 110), (128, 128)), ((64, 48), (17, 23)),
+                                     ((256, 256), (10, 10)), ((10, 10), (20, 20)), ((1, 1), (9, 5)),
+                                     ((5, 1), (3, 7)), ((300, 2), (2, 300))])
+def test_resize_bit_exact(kc, orc, filt, src, dst):
+    (sw, sh), (dw, dh) = src, dst
+    p = splitmix_plane(SEED_A, 0, sh, sw) * np.float32(1.5) - np.float32(0.25)  # exercises the [0,1] clamp
+    if p.size >= 16:
+        p.reshape(-1)[:4] = [np.nan, np.inf, -np.inf, -0.0]
+    got = kc.resize_image(kc.SlotImage.from_planes([p]), (dw, dh), kc.ResizeFilter.parse(filt)).planes()[0]
+    want = orc.resize_plane(p, dw, dh, filt)
+    assert bit_equal(got, want), "%s %s->%s max ulp %s" % (filt, src, dst, max_ulp(got, want))
+
+
+def test_resize_two_pass_fallback_matches(kc, orc):
+    # a down-sampling window too wide for a 64 KiB LDS tile (needs > 4096 source columns per tile)
+    p = splitmix_plane(SEED_B, 1, 8, 8192)
+    got = kc.resize_image(kc.SlotImage.from_planes([p]), (12, 5), kc.ResizeFilter.Lanczos3).planes()[0]
+    assert bit_equal(got, orc.resize_plane(p, 12, 5, "Lanczos3"))
+
+
+def test_resize_1x1_value_broadcast_is_clamped_constant(kc, orc):
+    for v in (0.33, 1.0, 7.0, -3.0, float("nan"), -0.0):
+        img = kc.resize_image(kc.value_process(v), (6, 4))
+        want = orc.resize_plane(np.full((1, 1), v, np.float32), 6, 4, "Triangle")
+        assert bit_equal(img.planes()[0], want), v
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (31, 45), (1, 1), (2, 5), (256, 256)])
+def test_height_to_normal(kc, orc, shape):
+    h, w = shape
+    p = splitmix_plane(SEED_A, 2, h, w)
+    got = kc.height_to_normal_process(kc.SlotImage.from_planes([p]))
+    nx, ny, nz = orc.height_to_normal(p)
+    assert_planes(got.planes(), [nx, ny, nz, np.ones_like(p)], ulp=0, what="h2n")
+    assert kc.height_to_normal_process(None) is None
+    assert kc.height_to_normal_process(kc.SlotImage.from_value((2, 2), 0.0, True)) is None
+
+
+@pytest.mark.parametrize("srgb", [False, True])
+@pytest.mark.parametrize("shape", [(32, 32), (7, 13)])
+def test_to_u8(kc, orc, shape, srgb):
+    h, w = shape
+    planes = [with_edge_cases(p * np.float32(1.2) - np.float32(0.1), 1) for p in synthetic_rgba(SEED_B, h, w)]
+    got = kc.SlotImage.from_planes(planes).to_u8(srgb)
+    want = orc.to_u8(orc.Image(planes), srgb)
+    if srgb:
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1  # powf(2.4) within 1 ulp
+        assert (got != want).mean() < 1e-3
+    else:
+        assert np.array_equal(got, want)
+    gg = kc.SlotImage.from_planes(planes[:1]).to_u8(srgb)
+    wg = orc.to_u8(orc.Image(planes[:1]), srgb)
+    assert np.abs(gg.astype(int) - wg.astype(int)).max() <= (1 if srgb else 0)
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+def test_from_u8(kc, orc, channels):
+    rng = np.random.default_rng(7)
+    px = rng.integers(0, 256, (19, 23, channels), dtype=np.uint8)
+    got = kc.SlotImage.from_u8(px)
+    assert got.is_rgba()
+    assert_planes(got.planes(), orc.deconstruct_u8(px))
+
+
+def test_separate_combine_alias_planes(kc, orc):
+    h, w = 8, 12
+    a = synthetic_rgba(SEED_A, h, w)
+    parts = kc.separate_rgba_process(kc.SlotImage.from_planes(a))
+    for c in range(4):
+        assert_planes(parts[c].planes(), [a[c]])
+    comb = kc.combine_rgba_process([parts[3], None, parts[0], None])
+    assert_planes(comb.planes(), [a[3], np.zeros_like(a[0]), a[0], np.ones_like(a[0])])
+    dflt = kc.separate_rgba_process(None)
+    assert [d.size() for d in dflt] == [(1, 1)] * 4
+
+
+def test_calculate_size_policies(kc, orc):
+    sizes = [(128, 128), (256, 64), (64, 256), (128, 128)]
+    P = kc.ResizePolicy
+    for pol, name in ((P.MostPixels, "MostPixels"), (P.LeastPixels, "LeastPixels"), (P.LargestAxes, "LargestAxes"),
+                      (P.SmallestAxes, "SmallestAxes")):
+        assert kc.calculate_size(pol, sizes) == orc.calculate_size(name, sizes)
+    assert kc.calculate_size(P.MostPixels, []) == (1, 1)
+    assert kc.calculate_size(P.SpecificSize((7, 9)), sizes) == (7, 9)
+
+
+def test_wrapped_torch_memory_roundtrip(kc, orc):
+    """Planes can live in caller-owned device memory (torch tensors), zero-copy."""
+    import ctypes as C
+    import torch
+    from kanter_core_amd import _lib
+    L = _lib.load()
+    h, w = 64, 128
+    ta = torch.rand(h, w, device="cuda")
+    tb = torch.rand(h, w, device="cuda")
+    torch.cuda.synchronize()
+    pa, pb = C.c_void_p(), C.c_void_p()
+    assert L.kc_plane_wrap(ta.data_ptr(), w, h, w * 4, C.byref(pa)) == 0
+    assert L.kc_plane_wrap(tb.data_ptr(), w, h, w * 4, C.byref(pb)) == 0
+    ia, ib = C.c_void_p(), C.c_void_p()
+    L.kc_image_gray(pa, C.byref(ia))
+    L.kc_image_gray(pb, C.byref(ib))
+    got = kc.mix_process(kc.SlotImage(ia.value), kc.SlotImage(ib.value), kc.MixType.Multiply).planes()[0]
+    L.kc_plane_release(pa)
+    L.kc_plane_release(pb)
+    assert bit_equal(got, orc.mix_plane("Multiply", ta.cpu().numpy(), tb.cpu().numpy()))
