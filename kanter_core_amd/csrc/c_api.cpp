@@ -58,6 +58,10 @@ int kc_init(int device_ordinal)
         if (v >= 1) c.max_blocks = v;
     }
     if (const char *tp = std::getenv("KC_RESIZE_TWO_PASS")) c.resize_two_pass = std::atoi(tp) != 0;
+    if (const char *cu = std::getenv("KC_CHAIN_UNROLL")) {
+        int v = std::atoi(cu);
+        if (v == 1 || v == 2 || v == 4 || v == 8) c.chain_unroll = v;
+    }
     c.inited = true;
     return KC_OK;
 }

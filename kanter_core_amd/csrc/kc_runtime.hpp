@@ -74,6 +74,7 @@ struct Context {
     hipStream_t stream = nullptr;
     bool fusion = true;
     int max_blocks = 4096;
+    int chain_unroll = 0;  // float4 per thread per decode in the chain kernel; 0 = heuristic (KC_CHAIN_UNROLL)
     bool resize_two_pass = false;
     std::multimap<size_t, void *> free_blocks;
     uint64_t bytes_in_use = 0, bytes_cached = 0, launches = 0;

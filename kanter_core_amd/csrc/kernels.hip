@@ -34,46 +34,131 @@ static __device__ __forceinline__ float apply1(float acc, float x)
     else return x * acc;
 }
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// One step on the U float4 a thread owns, written OUT OF PLACE (dst = op(src, x)): the decode
+// loop ping-pongs between two register sets, so no switch arm ever has to preserve or merge the
+// old accumulator and the step costs exactly one packed VALU instruction per pixel pair.
 template <int CODE, int U>
-static __device__ __forceinline__ void apply4(float4 (&acc)[U], const float4 (&x)[U])
+static __device__ __forceinline__ void apply4(f4 (&dst)[U], const f4 (&src)[U], const f4 (&x)[U])
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        acc[u].x = apply1<CODE>(acc[u].x, x[u].x);
-        acc[u].y = apply1<CODE>(acc[u].y, x[u].y);
-        acc[u].z = apply1<CODE>(acc[u].z, x[u].z);
-        acc[u].w = apply1<CODE>(acc[u].w, x[u].w);
+        dst[u].x = apply1<CODE>(src[u].x, x[u].x);
+        dst[u].y = apply1<CODE>(src[u].y, x[u].y);
+        dst[u].z = apply1<CODE>(src[u].z, x[u].z);
+        dst[u].w = apply1<CODE>(src[u].w, x[u].w);
     }
 }
 
 template <int CODE, int U>
-static __device__ __forceinline__ void apply4c(float4 (&acc)[U], float c)
+static __device__ __forceinline__ void apply4c(f4 (&dst)[U], const f4 (&src)[U], float c)
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        acc[u].x = apply1<CODE>(acc[u].x, c);
-        acc[u].y = apply1<CODE>(acc[u].y, c);
-        acc[u].z = apply1<CODE>(acc[u].z, c);
-        acc[u].w = apply1<CODE>(acc[u].w, c);
+        dst[u].x = apply1<CODE>(src[u].x, c);
+        dst[u].y = apply1<CODE>(src[u].y, c);
+        dst[u].z = apply1<CODE>(src[u].z, c);
+        dst[u].w = apply1<CODE>(src[u].w, c);
     }
 }
 
-// The step code is wave-uniform (it comes from the kernel argument block), so this switch is a
-// scalar branch; each arm is straight-line VALU on the U float4 the thread owns.
-#define KC_SWITCH_CODE(APPLY)                                   \
-    switch (code) {                                             \
-    case CH_ADD: APPLY(CH_ADD); break;                          \
-    case CH_SUB_L: APPLY(CH_SUB_L); break;                      \
-    case CH_SUB_R: APPLY(CH_SUB_R); break;                      \
-    case CH_MUL: APPLY(CH_MUL); break;                          \
-    case CH_DIV_L: APPLY(CH_DIV_L); break;                      \
-    case CH_DIV_R: APPLY(CH_DIV_R); break;                      \
-    case CH_ADD_R: APPLY(CH_ADD_R); break;                      \
-    case CH_MUL_R: APPLY(CH_MUL_R); break;                      \
-    case CH_POW_L: if constexpr (POW) { APPLY(CH_POW_L); } break; \
-    case CH_POW_R: if constexpr (POW) { APPLY(CH_POW_R); } break; \
-    default: break;                                             \
+// The step word is wave-uniform (it comes from the kernel argument block through SMEM), so this
+// switch is a tree of scalar compares and branches; each arm is straight-line VALU on the U
+// float4 the thread owns.  The scalar unit is shared by the CU's four SIMDs, so the decode cost
+// per step is what bounds long chains: it is amortised over U * 4 pixels per lane.
+#define KC_CASES(SRCW, APPLY, DST, SRC)                                                  \
+    case ((SRCW) << 8) | CH_ADD: APPLY(CH_ADD, DST, SRC); break;                         \
+    case ((SRCW) << 8) | CH_SUB_L: APPLY(CH_SUB_L, DST, SRC); break;                     \
+    case ((SRCW) << 8) | CH_SUB_R: APPLY(CH_SUB_R, DST, SRC); break;                     \
+    case ((SRCW) << 8) | CH_MUL: APPLY(CH_MUL, DST, SRC); break;                         \
+    case ((SRCW) << 8) | CH_DIV_L: APPLY(CH_DIV_L, DST, SRC); break;                     \
+    case ((SRCW) << 8) | CH_DIV_R: APPLY(CH_DIV_R, DST, SRC); break;                     \
+    case ((SRCW) << 8) | CH_ADD_R: APPLY(CH_ADD_R, DST, SRC); break;                     \
+    case ((SRCW) << 8) | CH_MUL_R: APPLY(CH_MUL_R, DST, SRC); break;                     \
+    case ((SRCW) << 8) | CH_POW_L: if constexpr (POW) { APPLY(CH_POW_L, DST, SRC); } else __builtin_unreachable(); break; \
+    case ((SRCW) << 8) | CH_POW_R: if constexpr (POW) { APPLY(CH_POW_R, DST, SRC); } else __builtin_unreachable(); break;
+
+// Runs the whole step program on the U float4 a thread holds: acc = start, then every step.
+template <int K, int U, bool POW>
+static __device__ __forceinline__ void chain_run(const ChainProgram &P, const uint32_t b, const f4 (&in)[K][U], f4 (&acc)[U])
+{
+    if (P.start_src < 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = f4{ P.start_c[b], P.start_c[b], P.start_c[b], P.start_c[b] };
+    } else {
+        switch (P.start_src) {
+        case 0:
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = in[0][u];
+            break;
+        case 1:
+            if constexpr (K > 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = in[1][u];
+            }
+            break;
+        case 2:
+            if constexpr (K > 2) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = in[2][u];
+            }
+            break;
+        default:
+            if constexpr (K > 3) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = in[3][u];
+            }
+            break;
+        }
     }
+
+    // Decode: one scalar word + one scalar constant per step, fetched one step ahead so the
+    // SMEM latency hides behind the previous step's VALU work (the tables have a spare entry).
+    // Steps alternate acc -> alt -> acc; the host validates every word, so no arm is a no-op.
+    const uint32_t n_ops = P.n_ops;
+    const uint32_t *pw = P.op;
+    const float *pc = P.c[b];
+    uint32_t w_next = pw[0];
+    float c_next = pc[0];
+    f4 alt[U];
+#define KC_STEP(DST, SRC, IDX)                                                          \
+    {                                                                                   \
+    const uint32_t w = w_next;                                                      \
+    const float c = c_next;                                                         \
+    w_next = pw[(IDX) + 1];                                                         \
+    c_next = pc[(IDX) + 1];                                                         \
+    switch (w) {                                                                    \
+        KC_CASES(0, KC_APPLY_C, DST, SRC)                                           \
+        KC_CASES(1, KC_APPLY_0, DST, SRC)                                           \
+        KC_CASES(2, KC_APPLY_1, DST, SRC)                                           \
+        KC_CASES(3, KC_APPLY_2, DST, SRC)                                           \
+        KC_CASES(4, KC_APPLY_3, DST, SRC)                                           \
+    default: __builtin_unreachable();                                               \
+    }                                                                               \
+    }
+#define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, U>(DST, SRC, c)
+#define KC_APPLY_0(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[0])
+#define KC_APPLY_1(CODE, DST, SRC) if constexpr (K > 1) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0]); else __builtin_unreachable()
+#define KC_APPLY_2(CODE, DST, SRC) if constexpr (K > 2) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0]); else __builtin_unreachable()
+#define KC_APPLY_3(CODE, DST, SRC) if constexpr (K > 3) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0]); else __builtin_unreachable()
+    uint32_t i = 0;
+    for (; i + 1 < n_ops; i += 2) {
+        KC_STEP(alt, acc, i)
+        KC_STEP(acc, alt, i + 1)
+    }
+    if (i < n_ops) {
+        KC_STEP(alt, acc, i)
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = alt[u];
+    }
+#undef KC_STEP
+#undef KC_APPLY_C
+#undef KC_APPLY_0
+#undef KC_APPLY_1
+#undef KC_APPLY_2
+#undef KC_APPLY_3
+}
 
 // Fused Mix chain (src/node/mix.rs:136-192 applied N times without materialising the
 // intermediates).  K = distinct input planes, U = float4 per thread per iteration, POW = chain
@@ -85,20 +170,20 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
     const uint32_t b = blockIdx.y;
     const uint32_t total = P.rows * P.row_units;
     const bool flat = P.rows == 1;
-    const float4 *inp[K];
+    const f4 *inp[K];
     uint32_t ipitch[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        inp[k] = reinterpret_cast<const float4 *>(P.in[b][k]);
+        inp[k] = reinterpret_cast<const f4 *>(P.in[b][k]);
         ipitch[k] = P.in_pitch[b][k];
     }
-    float4 *outp = reinterpret_cast<float4 *>(P.out[b]);
+    f4 *outp = reinterpret_cast<f4 *>(P.out[b]);
     const uint32_t opitch = P.out_pitch[b];
     const uint32_t step = gridDim.x * (256u * U);
 
     for (uint32_t base = blockIdx.x * (256u * U) + threadIdx.x; base < total; base += step) {
-        float4 in[K][U];
-        float4 acc[U];
+        f4 in[K][U];
+        f4 acc[U];
         uint32_t ooff[U];
         bool valid[U];
 #pragma unroll
@@ -113,71 +198,10 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
             ooff[u] = row * opitch + col;
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                in[k][u] = valid[u] ? inp[k][row * ipitch[k] + col] : splat4(0.0f);
+                in[k][u] = valid[u] ? inp[k][row * ipitch[k] + col] : f4{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
 
-        if (P.start_src < 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = splat4(P.start_c[b]);
-        } else {
-            switch (P.start_src) {
-            case 0:
-#pragma unroll
-                for (int u = 0; u < U; ++u) acc[u] = in[0][u];
-                break;
-            case 1:
-                if constexpr (K > 1) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u] = in[1][u];
-                }
-                break;
-            case 2:
-                if constexpr (K > 2) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u] = in[2][u];
-                }
-                break;
-            default:
-                if constexpr (K > 3) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u] = in[3][u];
-                }
-                break;
-            }
-        }
-
-        for (uint32_t i = 0; i < P.n_ops; ++i) {
-            const int code = P.code[i];
-            const int src = P.src[i];
-            if (src < 0) {
-                const float c = P.c[b][i];
-#define KC_APPLY_C(CODE) apply4c<CODE, U>(acc, c)
-                KC_SWITCH_CODE(KC_APPLY_C)
-#undef KC_APPLY_C
-            } else if (src == 0) {
-#define KC_APPLY_0(CODE) apply4<CODE, U>(acc, in[0])
-                KC_SWITCH_CODE(KC_APPLY_0)
-#undef KC_APPLY_0
-            } else if (src == 1) {
-                if constexpr (K > 1) {
-#define KC_APPLY_1(CODE) apply4<CODE, U>(acc, in[1])
-                    KC_SWITCH_CODE(KC_APPLY_1)
-#undef KC_APPLY_1
-                }
-            } else if (src == 2) {
-                if constexpr (K > 2) {
-#define KC_APPLY_2(CODE) apply4<CODE, U>(acc, in[2])
-                    KC_SWITCH_CODE(KC_APPLY_2)
-#undef KC_APPLY_2
-                }
-            } else {
-                if constexpr (K > 3) {
-#define KC_APPLY_3(CODE) apply4<CODE, U>(acc, in[3])
-                    KC_SWITCH_CODE(KC_APPLY_3)
-#undef KC_APPLY_3
-                }
-            }
-        }
+        chain_run<K, U, POW>(P, b, in, acc);
 
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -192,16 +216,21 @@ __global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
     const uint32_t b = blockIdx.y;
     const uint32_t total = P.rows * P.row_units;
     const bool flat = P.rows == 1;
-    float4 *outp = reinterpret_cast<float4 *>(P.out[b]);
+    f4 *outp = reinterpret_cast<f4 *>(P.out[b]);
     const uint32_t opitch = P.out_pitch[b];
-    float4 acc[1];
-    acc[0] = splat4(P.start_c[b]);
+    f4 acc[1];
+    acc[0] = f4{ P.start_c[b], P.start_c[b], P.start_c[b], P.start_c[b] };
     for (uint32_t i = 0; i < P.n_ops; ++i) {
-        const int code = P.code[i];
+        const uint32_t w = P.op[i] & 0xffu;
         const float c = P.c[b][i];
-#define KC_APPLY_C(CODE) apply4c<CODE, 1>(acc, c)
-        KC_SWITCH_CODE(KC_APPLY_C)
+        f4 nxt[1];
+#define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, 1>(DST, SRC, c)
+        switch (w) {
+            KC_CASES(0, KC_APPLY_C, nxt, acc)
+        default: nxt[0] = acc[0]; break;
+        }
 #undef KC_APPLY_C
+        acc[0] = nxt[0];
     }
     const uint32_t step = gridDim.x * 256u;
     for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += step) {
@@ -228,22 +257,32 @@ static hipError_t launch_chain_k(const ChainProgram &p, dim3 grid, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_chain(const ChainProgram &p, int batch, bool has_pow, int max_blocks, hipStream_t s)
+template <int U, bool POW>
+static hipError_t launch_chain_u(const ChainProgram &p, int batch, uint64_t total, int max_blocks, hipStream_t s)
 {
-    if (batch < 1 || batch > KC_CHAIN_MAX_BATCH || p.n_ops > KC_CHAIN_MAX_OPS) return hipErrorInvalidValue;
+    uint64_t blocks = (total + 256 * U - 1) / (256 * U);
+    if (blocks > (uint64_t)max_blocks) blocks = max_blocks;
+    return launch_chain_k<U, POW>(p, dim3((unsigned)blocks, batch, 1), s);
+}
+
+hipError_t launch_chain(const ChainProgram &p, int batch, bool has_pow, int max_blocks, int unroll, hipStream_t s)
+{
+    if (batch < 1 || batch > KC_CHAIN_MAX_BATCH || p.n_ops > KC_CHAIN_MAX_OPS || p.n_ops < 1) return hipErrorInvalidValue;
     const uint64_t total = (uint64_t)p.rows * p.row_units;
     if (total == 0) return hipSuccess;
     if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    if (has_pow) {
-        constexpr int U = 1;
-        uint64_t blocks = (total + 256 * U - 1) / (256 * U);
-        if (blocks > (uint64_t)max_blocks) blocks = max_blocks;
-        return launch_chain_k<U, true>(p, dim3((unsigned)blocks, batch, 1), s);
+    if (has_pow) return launch_chain_u<1, true>(p, batch, total, max_blocks, s);
+    // unroll == 0: pick U.  The decode cost per step is amortised over U float4 per lane, the
+    // register budget is (K + 2) * 4 * U VGPRs: long chains on <= 2 planes take U = 8 (3 waves/SIMD),
+    // everything else U = 4 (6 waves/SIMD).  Measured on MI355X, 4096^2: profiles/r01_chain_unroll.md.
+    if (unroll == 0) unroll = (p.n_ops >= 24 && p.n_in <= 2) ? 8 : 4;
+    if (unroll > 4 && p.n_in > 2) unroll = 4;
+    switch (unroll) {
+    case 1: return launch_chain_u<1, false>(p, batch, total, max_blocks, s);
+    case 2: return launch_chain_u<2, false>(p, batch, total, max_blocks, s);
+    case 4: return launch_chain_u<4, false>(p, batch, total, max_blocks, s);
+    default: return launch_chain_u<8, false>(p, batch, total, max_blocks, s);
     }
-    constexpr int U = 2;
-    uint64_t blocks = (total + 256 * U - 1) / (256 * U);
-    if (blocks > (uint64_t)max_blocks) blocks = max_blocks;
-    return launch_chain_k<U, false>(p, dim3((unsigned)blocks, batch, 1), s);
 }
 
 // vec![v; n] (src/slot_image.rs:28-64): only when a constant plane must really exist in HBM.

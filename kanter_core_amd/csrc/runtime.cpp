@@ -209,10 +209,9 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
         else
             c = st.operand->cval;
         if (b == 0) {
-            P.code[i] = st.code;
-            P.src[i] = (int8_t)src;
+            P.op[i] = chain_op_word(st.code, src);
             if (st.code == CH_POW_L || st.code == CH_POW_R) bc.has_pow = true;
-        } else if (P.code[i] != st.code || P.src[i] != (int8_t)src) {
+        } else if (P.op[i] != chain_op_word(st.code, src)) {
             return false;
         }
         P.c[b][i] = c;
@@ -257,7 +256,7 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
         P.rows = p0->h;
         P.row_units = row_units;
     }
-    hipError_t e = launch_chain(P, batch, bc.has_pow, c.max_blocks, c.stream);
+    hipError_t e = launch_chain(P, batch, bc.has_pow, c.max_blocks, c.chain_unroll, c.stream);
     if (e != hipSuccess) {
         for (auto *o : outs) plane_release(o);
         return hip_fail(e, "launch_chain");
