@@ -281,7 +281,6 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 
 int planes_force(kc_plane *const *planes, int n)
 {
-    KC_TRY(need_init());
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
     std::vector<kc_plane *> todo;
     for (int i = 0; i < n; ++i) {
@@ -291,6 +290,8 @@ int planes_force(kc_plane *const *planes, int n)
         for (auto *q : todo) dup |= (q == p);
         if (!dup) todo.push_back(p);
     }
+    if (todo.empty()) return KC_OK;  // constants / resident planes: nothing to launch
+    KC_TRY(need_init());
     size_t i = 0;
     while (i < todo.size()) {
         BuiltChain bc;

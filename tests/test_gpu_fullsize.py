@@ -1,0 +1,132 @@
+"""GPU parity at BASELINE.json's full sizes: against the oracle where it finishes in seconds,
+and through size-independent properties (fused == unfused bit for bit, crop equivalence of
+pointwise graphs, alpha == 1, resize idempotence on constants) where it does not."""
+import numpy as np
+import pytest
+
+from util import SEED_A, SEED_B, assert_planes, bit_equal, splitmix_plane
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kc():
+    import kanter_core_amd as kc
+    kc.init(0)
+    return kc
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as orc
+    orc.set_threads(8)
+    yield orc
+    orc.set_threads(1)
+
+
+@pytest.fixture(scope="module")
+def planes4096():
+    S = 4096
+    a = [splitmix_plane(SEED_A, c, S, S) for c in range(3)]
+    b = [splitmix_plane(SEED_B, c, S, S) for c in range(3)]
+    one = np.ones((S, S), np.float32)
+    return a + [one], b + [one]
+
+
+def chain(kc, x, bb, w, h, n):
+    white = kc.combine_rgba_process([kc.value_process(1.0)] * 3 + [None])
+    for i in range(1, n + 1):
+        if i & 1:
+            x = kc.mix_process(x, bb, kc.MixType.Multiply if (i >> 1) & 1 else kc.MixType.Add)
+        else:
+            x = kc.mix_process(kc.resize_image(white, (w, h)), x, kc.MixType.Subtract)
+    return x
+
+
+@pytest.mark.parametrize("op", ["Add", "Divide"])
+def test_config1_single_mix_4096_vs_oracle(kc, orc, planes4096, op):
+    """BASELINE config #1: one Mix node on two 4096x4096 f32x4 inputs."""
+    a, b = planes4096
+    got = kc.mix_process(kc.SlotImage.from_planes(a), kc.SlotImage.from_planes(b), kc.MixType.parse(op)).planes()
+    want = [orc.mix_plane(op, a[c], b[c]) for c in range(3)] + [np.ones_like(a[0])]
+    assert_planes(got, want, what="4096 " + op)
+
+
+def test_config3_chain32_4096_fused_equals_unfused_equals_oracle(kc, orc, planes4096):
+    """BASELINE headline: 32-node linear mix/invert graph at 4096x4096."""
+    a, b = planes4096
+    S = 4096
+    ia, ib = kc.SlotImage.from_planes(a), kc.SlotImage.from_planes(b)
+    fused = chain(kc, ia, ib, S, S, 32).planes()
+    kc.set_fusion(False)
+    try:
+        unfused = chain(kc, ia, ib, S, S, 32).planes()
+    finally:
+        kc.set_fusion(True)
+    assert_planes(fused, unfused, what="fused vs unfused")
+    assert bit_equal(fused[3], np.ones((S, S), np.float32))
+    want = orc.chain32(a, b, 32)
+    assert_planes(fused, want, what="fused vs oracle")
+
+
+def test_config3_chain32_8192_crop_equivalence(kc, orc):
+    """8192x8192 (BASELINE config #3 size): a pointwise graph commutes with cropping, so the
+    oracle on a 192x160 crop of the inputs must equal the same crop of the GPU's full result."""
+    S = 8192
+    a = [splitmix_plane(SEED_A, c, S, S) for c in range(3)]
+    b = [splitmix_plane(SEED_B, c, S, S) for c in range(3)]
+    one = kc.SlotImage.from_value((S, S), 1.0, False).plane_handles  # noqa: F841 (keeps API exercised)
+    ia = kc.combine_rgba_process([kc.SlotImage.from_planes([p]) for p in a] + [None])
+    ib = kc.combine_rgba_process([kc.SlotImage.from_planes([p]) for p in b] + [None])
+    got = chain(kc, ia, ib, S, S, 32).planes()
+    for (y, x) in ((0, 0), (4000, 5000), (S - 160, S - 192)):
+        ca = [p[y:y + 160, x:x + 192].copy() for p in a] + [np.ones((160, 192), np.float32)]
+        cb = [p[y:y + 160, x:x + 192].copy() for p in b] + [np.ones((160, 192), np.float32)]
+        want = orc.chain32(ca, cb, 32)
+        assert_planes([p[y:y + 160, x:x + 192] for p in got], want, what="crop %d,%d" % (y, x))
+
+
+def test_config2_resize_512_to_4096_and_blend_chain_vs_oracle(kc, orc, planes4096):
+    """BASELINE config #2: B 512^2 -> 4096^2 (Triangle, MostPixels) feeding a 3-node blend chain,
+    through the LiveGraph so the implicit resize pre-step runs per consuming node."""
+    a, _ = planes4096
+    S, s = 4096, 512
+    b = [splitmix_plane(SEED_B, c, s, s) for c in range(4)]
+    tp = kc.TextureProcessor.new()
+    lg = tp.new_live_graph()
+    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(a)), 0)
+    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(b)), 1)
+    na = lg.add_node(kc.Node.new(kc.NodeType.Embed(0)))
+    nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(1)))
+    n1 = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)))
+    n2 = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Multiply)))
+    n3 = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Subtract)))
+    lg.connect(na, n1, 0, 0)
+    lg.connect(nb, n1, 0, 1)
+    lg.connect(n1, n2, 0, 0)
+    lg.connect(na, n2, 0, 1)
+    lg.connect(n2, n3, 0, 0)
+    lg.connect(nb, n3, 0, 1)
+    got = lg.await_clean(n3).slot_data(n3, 0).image.planes()
+    bu = [orc.resize_plane(p, S, S, "Triangle") for p in b[:3]]
+    want = []
+    for c in range(3):
+        x1 = orc.mix_plane("Add", a[c], bu[c])
+        x2 = orc.mix_plane("Multiply", x1, a[c])
+        want.append(orc.mix_plane("Subtract", x2, bu[c]))
+    want.append(np.ones((S, S), np.float32))
+    assert_planes(got, want, what="config #2")
+    assert lg.slot_data_size(n3, 0) == (S, S)
+
+
+def test_height_to_normal_4096_vs_oracle(kc, orc):
+    p = splitmix_plane(SEED_A, 1, 4096, 4096)
+    got = kc.height_to_normal_process(kc.SlotImage.from_planes([p])).planes()
+    nx, ny, nz = orc.height_to_normal(p)
+    assert_planes(got, [nx, ny, nz, np.ones_like(p)], what="h2n 4096")
+
+
+def test_to_u8_4096_vs_oracle(kc, orc, planes4096):
+    a, _ = planes4096
+    got = kc.SlotImage.from_planes(a).to_u8()
+    assert np.array_equal(got, orc.to_u8(orc.Image(a)))
