@@ -57,7 +57,8 @@ int kc_init(int device_ordinal)
         int v = std::atoi(mb);
         if (v >= 1) c.max_blocks = v;
     }
-    if (const char *tp = std::getenv("KC_RESIZE_TWO_PASS")) c.resize_two_pass = std::atoi(tp) != 0;
+    if (const char *rm = std::getenv("KC_RESIZE_MODE")) c.resize_mode = std::atoi(rm);
+    if (const char *rt = std::getenv("KC_RESIZE_TILE_H")) c.resize_tile_h = std::atoi(rt);
     if (const char *cu = std::getenv("KC_CHAIN_UNROLL")) {
         int v = std::atoi(cu);
         if (v == 1 || v == 2 || v == 4 || v == 8) c.chain_unroll = v;

@@ -80,10 +80,15 @@ hipError_t launch_resize_vertical(const float *src, uint32_t spitch, uint32_t sw
                                   uint32_t dh, TapsDev v, hipStream_t s);
 hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *dst, uint32_t dpitch, uint32_t dw,
                                     uint32_t dh, TapsDev h, hipStream_t s);
-// LDS-tiled single-pass resample; `ncap` = widest source-column window of any tile (from host).
+// LDS-tiled single-pass resample.  ncp / nrp = LDS pitch / rows of the staged source tile (>= the
+// widest source window any tile needs, from the host); LDS bytes = resize_lds_bytes(...).
+inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t nrp, uint32_t v_stride)
+{
+    return ((size_t)nrp * ncp + (size_t)tile_h * ncp + 2u * tile_h + (size_t)tile_h * v_stride) * sizeof(float);
+}
 hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
-                             uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncap,
-                             hipStream_t s);
+                             uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
+                             uint32_t nrp, hipStream_t s);
 hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, float *nx, float *ny,
                                    float *nz, uint32_t opitch, hipStream_t s);
 hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,

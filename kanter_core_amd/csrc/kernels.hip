@@ -375,60 +375,129 @@ hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *ds
     return hipGetLastError();
 }
 
-// Single-pass LDS-tiled form: each workgroup owns a tile_h x tile_w output tile, builds the
-// vertical-pass intermediate for exactly the source columns the tile needs in LDS
-// (tile_h x ncap floats) and runs the horizontal pass out of LDS.  The intermediate never
-// touches HBM: algorithmic bytes per output pixel = 4 * (1 + in_px / out_px).
+// Single-pass LDS-tiled form: each workgroup owns a tile_h x tile_w output tile.
+//   stage   the tile's source neighbourhood (nr x nc floats, coalesced rows) and the vertical tap
+//           table of its rows go to LDS once -- the only HBM reads of the kernel;
+//   phase 1 vertical pass LDS -> LDS: the intermediate the two-pass form would write to HBM
+//           (tile_h x nc floats) never leaves the CU;
+//   phase 2 horizontal pass out of LDS: every thread owns 4 consecutive output columns for the
+//           whole tile, so its tap windows and (TAPS > 0) its weights sit in registers and the
+//           four results leave as one 16-byte store.
+// Same operands, same order, same roundings as the two-pass form: bit-identical output.
+// Algorithmic bytes per output pixel = 4 * (1 + in_px / out_px).
+template <int TAPS>  // max horizontal taps held in registers; 0 = any count, weights read per use
 __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict__ src, uint32_t spitch,
                                                          float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
                                                          uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
-                                                         uint32_t tile_h, uint32_t ncap)
+                                                         uint32_t tile_h, uint32_t ncp, uint32_t nrp)
 {
-    extern __shared__ __attribute__((aligned(16))) float tmp[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *srcT = lds;                          // nrp x ncp
+    float *tmp = srcT + nrp * ncp;              // tile_h x ncp
+    uint32_t *vl = reinterpret_cast<uint32_t *>(tmp + tile_h * ncp);
+    uint32_t *vn = vl + tile_h;
+    float *vw = reinterpret_cast<float *>(vn + tile_h);  // tile_h x V.stride
+
     const uint32_t x0 = blockIdx.x * tile_w;
     const uint32_t y0 = blockIdx.y * tile_h;
     const uint32_t x1 = min(x0 + tile_w, dw);
     const uint32_t y1 = min(y0 + tile_h, dh);
-    const uint32_t tw = x1 - x0;
     const uint32_t th = y1 - y0;
     const uint32_t c0 = H.left[x0];
-    const uint32_t c1 = H.left[x1 - 1] + H.count[x1 - 1];
-    const uint32_t nc = c1 - c0;  // <= ncap (host-checked)
+    const uint32_t nc = H.left[x1 - 1] + H.count[x1 - 1] - c0;  // <= ncp (host-checked)
+    const uint32_t r0 = V.left[y0];
+    const uint32_t nr = V.left[y1 - 1] + V.count[y1 - 1] - r0;  // <= nrp (host-checked)
 
-    for (uint32_t i = threadIdx.x; i < th * nc; i += 256u) {
-        const uint32_t ty = i / nc;
-        const uint32_t cc = i - ty * nc;
-        const uint32_t oy = y0 + ty;
-        const uint32_t left = V.left[oy];
-        const uint32_t n = V.count[oy];
-        const float *w = V.w + (size_t)oy * V.stride;
-        float t = 0.0f;
-        for (uint32_t j = 0; j < n; ++j) t += src[(size_t)(left + j) * spitch + c0 + cc] * w[j];
-        tmp[ty * ncap + cc] = t;
+    // this thread's 4 output columns (fetched first so the loads overlap the staging below)
+    const uint32_t col_groups = tile_w / 4;         // threads across one tile row
+    const uint32_t row_groups = 256u / col_groups;  // tile rows in flight
+    const uint32_t cg = threadIdx.x % col_groups;
+    const uint32_t rg = threadIdx.x / col_groups;
+    const uint32_t ox = x0 + 4 * cg;
+    uint32_t hl[4], hn[4];
+    const float *wh[4];
+    float wreg[4][TAPS > 0 ? TAPS : 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t x = min(ox + e, x1 - 1);
+        hl[e] = H.left[x] - c0;
+        hn[e] = H.count[x];
+        wh[e] = H.w + (size_t)x * H.stride;
+        if constexpr (TAPS > 0) {
+#pragma unroll
+            for (int j = 0; j < TAPS; ++j) wreg[e][j] = (uint32_t)j < hn[e] ? wh[e][j] : 0.0f;
+        }
+    }
+
+    for (uint32_t i = threadIdx.x; i < th; i += 256u) {
+        vl[i] = V.left[y0 + i] - r0;
+        vn[i] = V.count[y0 + i];
+    }
+    for (uint32_t i = threadIdx.x; i < th * V.stride; i += 256u) vw[i] = V.w[(size_t)y0 * V.stride + i];
+    // i / nc by multiply-high: exact here because i < (nrp + tile_h) * ncp <= 2^14 (64 KiB of LDS)
+    const uint32_t nc_magic = nc > 1 ? 0xFFFFFFFFu / nc + 1u : 0u;
+    auto div_nc = [&](uint32_t i) { return nc > 1 ? __umulhi(i, nc_magic) : i; };
+    for (uint32_t i = threadIdx.x; i < nr * nc; i += 256u) {
+        const uint32_t r = div_nc(i);
+        const uint32_t c = i - r * nc;
+        srcT[r * ncp + c] = src[(size_t)(r0 + r) * spitch + c0 + c];
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < th * tw; i += 256u) {
-        const uint32_t ty = i / tw;
-        const uint32_t tx = i - ty * tw;
-        const uint32_t ox = x0 + tx;
-        const uint32_t left = H.left[ox] - c0;
-        const uint32_t n = H.count[ox];
-        const float *w = H.w + (size_t)ox * H.stride;
-        const float *row = tmp + ty * ncap + left;
+
+    for (uint32_t i = threadIdx.x; i < th * nc; i += 256u) {
+        const uint32_t ty = div_nc(i);
+        const uint32_t cc = i - ty * nc;
+        const uint32_t n = vn[ty];
+        const float *w = vw + ty * V.stride;
+        const float *col = srcT + vl[ty] * ncp + cc;
         float t = 0.0f;
-        for (uint32_t j = 0; j < n; ++j) t += row[j] * w[j];
-        dst[(size_t)(y0 + ty) * dpitch + ox] = clamp01_nan_passthrough(t);
+        for (uint32_t j = 0; j < n; ++j) t += col[j * ncp] * w[j];
+        tmp[ty * ncp + cc] = t;
+    }
+    __syncthreads();
+
+    if (ox >= x1) return;
+    for (uint32_t ty = rg; ty < th; ty += row_groups) {
+        const float *row = tmp + ty * ncp;
+        float res[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = 0.0f;
+            if constexpr (TAPS > 0) {
+                t += row[hl[e]] * wreg[e][0];  // every window has at least one tap
+#pragma unroll
+                for (int j = 1; j < TAPS; ++j)
+                    if ((uint32_t)j < hn[e]) t += row[hl[e] + j] * wreg[e][j];
+            } else {
+                for (uint32_t j = 0; j < hn[e]; ++j) t += row[hl[e] + j] * wh[e][j];
+            }
+            res[e] = clamp01_nan_passthrough(t);
+        }
+        float *o = dst + (size_t)(y0 + ty) * dpitch + ox;
+        if (ox + 3 < x1) {
+            *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ox + e < x1) o[e] = res[e];
+        }
     }
 }
 
 hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
-                             uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncap,
-                             hipStream_t s)
+                             uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
+                             uint32_t nrp, hipStream_t s)
 {
     if (dw == 0 || dh == 0) return hipSuccess;
-    const size_t lds = (size_t)tile_h * ncap * sizeof(float);
+    if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
+    const size_t lds = resize_lds_bytes(tile_h, ncp, nrp, v.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h);
-    resize_lds_kernel<<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncap);
+    if (h.stride <= 2)
+        resize_lds_kernel<2><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    else if (h.stride <= 4)
+        resize_lds_kernel<4><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    else
+        resize_lds_kernel<0><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
     return hipGetLastError();
 }
 

@@ -168,16 +168,20 @@ static int resize_plane(kc_plane *src, kc_size size, int filter, kc_plane **out)
     KC_TRY(plane_new_mem(size.width, size.height, &dst));
     const uint32_t spitch = (uint32_t)(src->pitch / 4), dpitch = (uint32_t)(dst->pitch / 4);
 
-    // LDS-tiled single pass when the vertical-pass intermediate of one tile fits in 64 KiB of
-    // LDS; otherwise (very large down-sampling windows) two passes through an HBM intermediate.
-    static const uint32_t tiles[][2] = { { 128, 16 }, { 64, 16 }, { 64, 8 }, { 32, 8 }, { 16, 8 }, { 16, 4 } };
+    // LDS-tiled single pass when one tile's source neighbourhood + vertical-pass intermediate fit
+    // in 64 KiB of LDS (every up-sample, moderate down-samples); otherwise (very wide windows) two
+    // passes through an HBM intermediate.  Bigger tiles first: they amortise the table fetches.
+    static const uint32_t tiles[][2] = { { 256, 64 }, { 256, 32 }, { 256, 16 }, { 128, 16 }, { 64, 16 },
+                                         { 64, 8 },   { 32, 8 },   { 16, 8 },   { 16, 4 } };
     bool done = false;
-    if (!c.resize_two_pass) {
+    if (c.resize_mode != 3) {
         for (auto &tl : tiles) {
-            const uint32_t ncap = tile_ncap(th->host, size.width, tl[0]);
-            if ((size_t)tl[1] * ncap * sizeof(float) <= 64 * 1024) {
+            if (c.resize_tile_h > 0 && tl[1] != (uint32_t)c.resize_tile_h && tl[0] == 256) continue;
+            const uint32_t ncp = tile_ncap(th->host, size.width, tl[0]) | 1u;  // odd pitch spreads LDS banks
+            const uint32_t nrp = tile_ncap(tv->host, size.height, tl[1]);
+            if (resize_lds_bytes(tl[1], ncp, nrp, tv->dev.stride) <= 64 * 1024) {
                 hipError_t e = launch_resize_lds(src->dptr, spitch, dst->dptr, dpitch, size.width, size.height, tv->dev,
-                                                 th->dev, tl[0], tl[1], ncap, c.stream);
+                                                 th->dev, tl[0], tl[1], ncp, nrp, c.stream);
                 if (e != hipSuccess) {
                     plane_release(dst);
                     return hip_fail(e, "launch_resize_lds");
