@@ -126,7 +126,7 @@ def main():
         # fused: R,G,B of A and B read once (24 B/px), R,G,B of the result written once (12 B/px);
         # alpha is a constant plane (0 B).  DESIGN.md "Kernels".
         alg_bytes = 36.0 * S * S
-        kernel = "chain_kernel<2,%d,false>" % (8 if N >= 24 else 4)
+        kernel = "chain_kernel<2,4,0>"
         desc = ("%d-node linear Mix graph (Add/Multiply alternating with invert = Mix(Subtract)(1, x)), "
                 "%dx%d f32x4 per GPU, SURVEY 8(d) config #3" % (N, S, S))
     elif args.workload == "mix1":
@@ -143,7 +143,7 @@ def main():
             lg.connect(na, m, 0, 0)
             lg.await_clean(m)
 
-        node_px, alg_bytes, kernel = float(S) * S, 36.0 * S * S, "chain_kernel<2,4,false>"
+        node_px, alg_bytes, kernel = float(S) * S, 36.0 * S * S, "chain_kernel<2,4,0>"
         desc = "single Mix(Add) node, two %dx%d f32x4 inputs, BASELINE config #1" % (S, S)
     elif args.workload == "resize_blend":
         s_small = S // 8
@@ -170,7 +170,7 @@ def main():
         # two resizes of B (one per consuming node, as the reference does): 4 planes x 4 B written +
         # source read each; fused 3-node chain: A (3 planes) + two B-up (3 planes each) read, 3 written
         alg_bytes = 2 * 4 * 4.0 * (S * S + s_small * s_small) + (3 + 3 + 3 + 3) * 4.0 * S * S
-        kernel = "resize_lds_kernel + chain_kernel<3,4,false>"
+        kernel = "resize_lds_kernel + chain_kernel<3,4,0>"
         desc = "B %d^2 -> %d^2 Triangle resize (per consuming node) + 3-node blend chain, BASELINE config #2" % (s_small, S)
     else:  # fanin
         n_branches, sub_nodes = 8, 16
@@ -237,7 +237,7 @@ def main():
 
         node_px = float(len(mine) * sub_nodes + (n_branches - 1 if rank == 0 else 0)) * S * S
         alg_bytes = len(mine) * 36.0 * S * S + (((n_branches * 3 + 3) * 4.0 * S * S) if rank == 0 else 0.0)
-        kernel = "chain_kernel<2,4,false> + RCCL gather + chain_kernel<4,4,false>"
+        kernel = "chain_kernel<2,4,false> + RCCL gather + chain_kernel<4,4,0>"
         desc = "8 independent 16-node subgraphs at %dx%d f32x4, RCCL gather to rank 0, 7-node Mix(Add) tree, BASELINE config #4" % (S, S)
 
     def barrier():

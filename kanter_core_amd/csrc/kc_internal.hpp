@@ -35,8 +35,14 @@ enum ChainCode : uint8_t {
     CH_DIV_R = 5,  // x / acc
     CH_POW_L = 6,  // acc ^ x
     CH_POW_R = 7,  // x ^ acc
-    CH_ADD_R = 8,  // x + acc (kept distinct so NaN payload order matches l + r)
-    CH_MUL_R = 9   // x * acc
+    CH_ADD_R = 8,  // x + acc: host-side only, canonicalised to CH_ADD before launch (same IEEE sum)
+    CH_MUL_R = 9   // x * acc: host-side only, canonicalised to CH_MUL
+};
+
+// word: bits 0-7 ChainCode, bits 8-15 operand source (0 = the constant c, k + 1 = input plane k).
+struct ChainStepRec {
+    uint32_t word;
+    float c;
 };
 
 struct ChainProgram {
@@ -45,16 +51,14 @@ struct ChainProgram {
     uint32_t row_units;  // vector units (float4 or float) per row; rows * row_units = work items
     uint32_t rows;
     int32_t start_src;  // input index, or -1: start from start_c
-    // One 32-bit word per step so the decode is a scalar (SMEM) load: bits 0-7 ChainCode,
-    // bits 8-15 operand source (0 = constant c[b][i], k + 1 = input plane k).
-    // Both tables carry one spare entry so the decode loop can prefetch step i + 1 unconditionally.
-    uint32_t op[KC_CHAIN_MAX_OPS + 1];
     const float *in[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];
     uint32_t in_pitch[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];  // in vector units
     float *out[KC_CHAIN_MAX_BATCH];
     uint32_t out_pitch[KC_CHAIN_MAX_BATCH];
     float start_c[KC_CHAIN_MAX_BATCH];
-    float c[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_OPS + 1];
+    // One 8-byte record per step and channel so the decode is a single scalar (SMEM) load; one
+    // spare record lets the loop prefetch step i + 1 unconditionally.
+    ChainStepRec step[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_OPS + 1];
 };
 
 // Per-axis tap table of the separable resampler, resident in HBM.
@@ -73,7 +77,8 @@ struct Operand {
 };
 
 // ---- kernel launchers (kernels.hip).  All enqueue on `s` and return hipGetLastError(). ----
-hipError_t launch_chain(const ChainProgram &p, int batch, bool has_pow, int max_blocks, int unroll, hipStream_t s);
+// mode: 0 = {+, -, *} only, 1 = + divide, 2 = + pow
+hipError_t launch_chain(const ChainProgram &p, int batch, int mode, int max_blocks, int unroll, hipStream_t s);
 inline uint32_t chain_op_word(uint8_t code, int src) { return (uint32_t)code | ((uint32_t)(src + 1) << 8); }
 hipError_t launch_fill(float *dst, uint32_t pitch_floats, uint32_t w, uint32_t h, float v, hipStream_t s);
 hipError_t launch_resize_vertical(const float *src, uint32_t spitch, uint32_t sw, float *tmp, uint32_t tpitch,

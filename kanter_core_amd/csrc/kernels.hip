@@ -63,24 +63,28 @@ static __device__ __forceinline__ void apply4c(f4 (&dst)[U], const f4 (&src)[U],
     }
 }
 
-// The step word is wave-uniform (it comes from the kernel argument block through SMEM), so this
-// switch is a tree of scalar compares and branches; each arm is straight-line VALU on the U
-// float4 the thread owns.  The scalar unit is shared by the CU's four SIMDs, so the decode cost
-// per step is what bounds long chains: it is amortised over U * 4 pixels per lane.
-#define KC_CASES(SRCW, APPLY, DST, SRC)                                                  \
-    case ((SRCW) << 8) | CH_ADD: APPLY(CH_ADD, DST, SRC); break;                         \
-    case ((SRCW) << 8) | CH_SUB_L: APPLY(CH_SUB_L, DST, SRC); break;                     \
-    case ((SRCW) << 8) | CH_SUB_R: APPLY(CH_SUB_R, DST, SRC); break;                     \
-    case ((SRCW) << 8) | CH_MUL: APPLY(CH_MUL, DST, SRC); break;                         \
-    case ((SRCW) << 8) | CH_DIV_L: APPLY(CH_DIV_L, DST, SRC); break;                     \
-    case ((SRCW) << 8) | CH_DIV_R: APPLY(CH_DIV_R, DST, SRC); break;                     \
-    case ((SRCW) << 8) | CH_ADD_R: APPLY(CH_ADD_R, DST, SRC); break;                     \
-    case ((SRCW) << 8) | CH_MUL_R: APPLY(CH_MUL_R, DST, SRC); break;                     \
-    case ((SRCW) << 8) | CH_POW_L: if constexpr (POW) { APPLY(CH_POW_L, DST, SRC); } else __builtin_unreachable(); break; \
-    case ((SRCW) << 8) | CH_POW_R: if constexpr (POW) { APPLY(CH_POW_R, DST, SRC); } else __builtin_unreachable(); break;
+// Decode.  The step record {word, constant} is wave-uniform (kernel argument block, read through
+// SMEM one step ahead), so the dispatch is scalar compares and branches and each arm is
+// straight-line VALU on the U float4 the thread owns.  PMC shows the kernel is ISSUE-bound for
+// long chains (every instruction, scalar or vector, costs the wave ~4 issue cycles), so the
+// scalar path is kept short: one pointer, one s_load_dwordx2 per step, a 2-level switch (operand
+// source, then op), and only the arms the program can contain -- MODE 0 = {+, -, *}, 1 = + divide,
+// 2 = + pow (f64 pow call).  x + acc / x * acc are canonicalised to acc + x / acc * x on the host.
+#define KC_CODE_SWITCH(APPLY, DST, SRC)                                                   \
+    switch (code) {                                                                       \
+    case CH_ADD: APPLY(CH_ADD, DST, SRC); break;                                          \
+    case CH_SUB_L: APPLY(CH_SUB_L, DST, SRC); break;                                      \
+    case CH_SUB_R: APPLY(CH_SUB_R, DST, SRC); break;                                      \
+    case CH_MUL: APPLY(CH_MUL, DST, SRC); break;                                          \
+    case CH_DIV_L: if constexpr (MODE >= 1) { APPLY(CH_DIV_L, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_DIV_R: if constexpr (MODE >= 1) { APPLY(CH_DIV_R, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_POW_L: if constexpr (MODE >= 2) { APPLY(CH_POW_L, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_POW_R: if constexpr (MODE >= 2) { APPLY(CH_POW_R, DST, SRC); } else __builtin_unreachable(); break; \
+    default: __builtin_unreachable();                                                     \
+    }
 
 // Runs the whole step program on the U float4 a thread holds: acc = start, then every step.
-template <int K, int U, bool POW>
+template <int K, int U, int MODE>
 static __device__ __forceinline__ void chain_run(const ChainProgram &P, const uint32_t b, const f4 (&in)[K][U], f4 (&acc)[U])
 {
     if (P.start_src < 0) {
@@ -113,35 +117,32 @@ static __device__ __forceinline__ void chain_run(const ChainProgram &P, const ui
         }
     }
 
-    // Decode: one scalar word + one scalar constant per step, fetched one step ahead so the
-    // SMEM latency hides behind the previous step's VALU work (the tables have a spare entry).
-    // Steps alternate acc -> alt -> acc; the host validates every word, so no arm is a no-op.
+    // Steps alternate acc -> alt -> acc (no arm ever merges register sets); the host validates
+    // every record, so unknown words cannot occur.
     const uint32_t n_ops = P.n_ops;
-    const uint32_t *pw = P.op;
-    const float *pc = P.c[b];
-    uint32_t w_next = pw[0];
-    float c_next = pc[0];
+    const ChainStepRec *ps = P.step[b];
+    ChainStepRec s_next = ps[0];
     f4 alt[U];
-#define KC_STEP(DST, SRC, IDX)                                                          \
-    {                                                                                   \
-    const uint32_t w = w_next;                                                      \
-    const float c = c_next;                                                         \
-    w_next = pw[(IDX) + 1];                                                         \
-    c_next = pc[(IDX) + 1];                                                         \
-    switch (w) {                                                                    \
-        KC_CASES(0, KC_APPLY_C, DST, SRC)                                           \
-        KC_CASES(1, KC_APPLY_0, DST, SRC)                                           \
-        KC_CASES(2, KC_APPLY_1, DST, SRC)                                           \
-        KC_CASES(3, KC_APPLY_2, DST, SRC)                                           \
-        KC_CASES(4, KC_APPLY_3, DST, SRC)                                           \
-    default: __builtin_unreachable();                                               \
-    }                                                                               \
-    }
 #define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, U>(DST, SRC, c)
 #define KC_APPLY_0(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[0])
-#define KC_APPLY_1(CODE, DST, SRC) if constexpr (K > 1) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0]); else __builtin_unreachable()
-#define KC_APPLY_2(CODE, DST, SRC) if constexpr (K > 2) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0]); else __builtin_unreachable()
-#define KC_APPLY_3(CODE, DST, SRC) if constexpr (K > 3) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0]); else __builtin_unreachable()
+#define KC_APPLY_1(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0])
+#define KC_APPLY_2(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0])
+#define KC_APPLY_3(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0])
+#define KC_STEP(DST, SRC, IDX)                                                          \
+    {                                                                                   \
+        const uint32_t code = s_next.word & 0xffu;                                      \
+        const uint32_t srcsel = s_next.word >> 8;                                       \
+        const float c = s_next.c;                                                       \
+        s_next = ps[(IDX) + 1];                                                         \
+        switch (srcsel) {                                                               \
+        case 0: KC_CODE_SWITCH(KC_APPLY_C, DST, SRC) break;                             \
+        case 1: KC_CODE_SWITCH(KC_APPLY_0, DST, SRC) break;                             \
+        case 2: if constexpr (K > 1) { KC_CODE_SWITCH(KC_APPLY_1, DST, SRC) } else __builtin_unreachable(); break; \
+        case 3: if constexpr (K > 2) { KC_CODE_SWITCH(KC_APPLY_2, DST, SRC) } else __builtin_unreachable(); break; \
+        case 4: if constexpr (K > 3) { KC_CODE_SWITCH(KC_APPLY_3, DST, SRC) } else __builtin_unreachable(); break; \
+        default: __builtin_unreachable();                                               \
+        }                                                                               \
+    }
     uint32_t i = 0;
     for (; i + 1 < n_ops; i += 2) {
         KC_STEP(alt, acc, i)
@@ -161,10 +162,9 @@ static __device__ __forceinline__ void chain_run(const ChainProgram &P, const ui
 }
 
 // Fused Mix chain (src/node/mix.rs:136-192 applied N times without materialising the
-// intermediates).  K = distinct input planes, U = float4 per thread per iteration, POW = chain
-// contains a pow step (keeps the f64 pow out of the lean instantiations).
+// intermediates).  K = distinct input planes, U = float4 per thread per decode, MODE = op set.
 // Algorithmic HBM bytes per pixel: 4 * (planes read + 1 written), whatever N is.
-template <int K, int U, bool POW>
+template <int K, int U, int MODE>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
 {
     const uint32_t b = blockIdx.y;
@@ -184,33 +184,37 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
     for (uint32_t base = blockIdx.x * (256u * U) + threadIdx.x; base < total; base += step) {
         f4 in[K][U];
         f4 acc[U];
-        uint32_t ooff[U];
-        bool valid[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t idx = base + u * 256u;
-            valid[u] = idx < total;
             uint32_t row = 0, col = idx;
             if (!flat) {
                 row = idx / P.row_units;
                 col = idx - row * P.row_units;
             }
-            ooff[u] = row * opitch + col;
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                in[k][u] = valid[u] ? inp[k][row * ipitch[k] + col] : f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                in[k][u] = idx < total ? inp[k][row * ipitch[k] + col] : f4{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
 
-        chain_run<K, U, POW>(P, b, in, acc);
+        chain_run<K, U, MODE>(P, b, in, acc);
 
+        // output offsets are recomputed here rather than kept live across the program (VGPRs)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (valid[u]) outp[ooff[u]] = acc[u];
+        for (int u = 0; u < U; ++u) {
+            const uint32_t idx = base + u * 256u;
+            uint32_t row = 0, col = idx;
+            if (!flat) {
+                row = idx / P.row_units;
+                col = idx - row * P.row_units;
+            }
+            if (idx < total) outp[row * opitch + col] = acc[u];
+        }
     }
 }
 
 // Zero-input chain (constant start, constant operands only): still one pass of stores.
-template <int U, bool POW>
+template <int MODE>
 __global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
 {
     const uint32_t b = blockIdx.y;
@@ -221,14 +225,11 @@ __global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
     f4 acc[1];
     acc[0] = f4{ P.start_c[b], P.start_c[b], P.start_c[b], P.start_c[b] };
     for (uint32_t i = 0; i < P.n_ops; ++i) {
-        const uint32_t w = P.op[i] & 0xffu;
-        const float c = P.c[b][i];
+        const uint32_t code = P.step[b][i].word & 0xffu;
+        const float c = P.step[b][i].c;
         f4 nxt[1];
 #define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, 1>(DST, SRC, c)
-        switch (w) {
-            KC_CASES(0, KC_APPLY_C, nxt, acc)
-        default: nxt[0] = acc[0]; break;
-        }
+        KC_CODE_SWITCH(KC_APPLY_C, nxt, acc)
 #undef KC_APPLY_C
         acc[0] = nxt[0];
     }
@@ -243,45 +244,43 @@ __global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
     }
 }
 
-template <int U, bool POW>
+template <int U, int MODE>
 static hipError_t launch_chain_k(const ChainProgram &p, dim3 grid, hipStream_t s)
 {
     switch (p.n_in) {
-    case 0: chain_kernel_k0<U, POW><<<grid, 256, 0, s>>>(p); break;
-    case 1: chain_kernel<1, U, POW><<<grid, 256, 0, s>>>(p); break;
-    case 2: chain_kernel<2, U, POW><<<grid, 256, 0, s>>>(p); break;
-    case 3: chain_kernel<3, U, POW><<<grid, 256, 0, s>>>(p); break;
-    case 4: chain_kernel<4, U, POW><<<grid, 256, 0, s>>>(p); break;
+    case 0: chain_kernel_k0<MODE><<<grid, 256, 0, s>>>(p); break;
+    case 1: chain_kernel<1, U, MODE><<<grid, 256, 0, s>>>(p); break;
+    case 2: chain_kernel<2, U, MODE><<<grid, 256, 0, s>>>(p); break;
+    case 3: chain_kernel<3, U, MODE><<<grid, 256, 0, s>>>(p); break;
+    case 4: chain_kernel<4, U, MODE><<<grid, 256, 0, s>>>(p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-template <int U, bool POW>
+template <int U, int MODE>
 static hipError_t launch_chain_u(const ChainProgram &p, int batch, uint64_t total, int max_blocks, hipStream_t s)
 {
     uint64_t blocks = (total + 256 * U - 1) / (256 * U);
     if (blocks > (uint64_t)max_blocks) blocks = max_blocks;
-    return launch_chain_k<U, POW>(p, dim3((unsigned)blocks, batch, 1), s);
+    return launch_chain_k<U, MODE>(p, dim3((unsigned)blocks, batch, 1), s);
 }
 
-hipError_t launch_chain(const ChainProgram &p, int batch, bool has_pow, int max_blocks, int unroll, hipStream_t s)
+hipError_t launch_chain(const ChainProgram &p, int batch, int mode, int max_blocks, int unroll, hipStream_t s)
 {
     if (batch < 1 || batch > KC_CHAIN_MAX_BATCH || p.n_ops > KC_CHAIN_MAX_OPS || p.n_ops < 1) return hipErrorInvalidValue;
     const uint64_t total = (uint64_t)p.rows * p.row_units;
     if (total == 0) return hipSuccess;
     if (total > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    if (has_pow) return launch_chain_u<1, true>(p, batch, total, max_blocks, s);
-    // unroll == 0: pick U.  The decode cost per step is amortised over U float4 per lane, the
-    // register budget is (K + 2) * 4 * U VGPRs: long chains on <= 2 planes take U = 8 (3 waves/SIMD),
-    // everything else U = 4 (6 waves/SIMD).  Measured on MI355X, 4096^2: profiles/r01_chain_unroll.md.
-    if (unroll == 0) unroll = (p.n_ops >= 24 && p.n_in <= 2) ? 8 : 4;
-    if (unroll > 4 && p.n_in > 2) unroll = 4;
+    if (mode >= 2) return launch_chain_u<1, 2>(p, batch, total, max_blocks, s);
+    if (mode == 1) return launch_chain_u<4, 1>(p, batch, total, max_blocks, s);
+    // U = float4 per lane per decode.  U = 4 (74-106 VGPRs, 4-6 waves/SIMD) is the measured optimum
+    // on MI355X for 1-64 step chains: U = 2 doubles the scalar decode work per pixel, U = 8 drops to
+    // 2-3 waves/SIMD (profiles/r01_chain_unroll.md).  KC_CHAIN_UNROLL overrides for tuning.
     switch (unroll) {
-    case 1: return launch_chain_u<1, false>(p, batch, total, max_blocks, s);
-    case 2: return launch_chain_u<2, false>(p, batch, total, max_blocks, s);
-    case 4: return launch_chain_u<4, false>(p, batch, total, max_blocks, s);
-    default: return launch_chain_u<8, false>(p, batch, total, max_blocks, s);
+    case 1: return launch_chain_u<1, 0>(p, batch, total, max_blocks, s);
+    case 2: return launch_chain_u<2, 0>(p, batch, total, max_blocks, s);
+    default: return launch_chain_u<4, 0>(p, batch, total, max_blocks, s);
     }
 }
 

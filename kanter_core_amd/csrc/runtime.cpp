@@ -172,7 +172,7 @@ Operand plane_operand(const kc_plane *p)
 struct BuiltChain {
     std::vector<const kc_plane *> inputs;  // distinct MEM planes, index = kernel input slot
     ChainProgram prog;
-    bool has_pow = false;
+    int mode = 0;  // 0 = {+,-,*}, 1 = + divide, 2 = + pow
 };
 
 static int input_index(std::vector<const kc_plane *> &ins, const kc_plane *p)
@@ -208,13 +208,19 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
             src = input_index(ins, st.operand);
         else
             c = st.operand->cval;
+        uint8_t code = st.code;
+        if (code == CH_ADD_R) code = CH_ADD;  // commutative: the same IEEE result
+        if (code == CH_MUL_R) code = CH_MUL;
+        const uint32_t word = chain_op_word(code, src);
         if (b == 0) {
-            P.op[i] = chain_op_word(st.code, src);
-            if (st.code == CH_POW_L || st.code == CH_POW_R) bc.has_pow = true;
-        } else if (P.op[i] != chain_op_word(st.code, src)) {
+            P.step[0][i].word = word;
+            if (code == CH_DIV_L || code == CH_DIV_R) bc.mode = bc.mode < 1 ? 1 : bc.mode;
+            if (code == CH_POW_L || code == CH_POW_R) bc.mode = 2;
+        } else if (P.step[0][i].word != word) {
             return false;
         }
-        P.c[b][i] = c;
+        P.step[b][i].word = word;
+        P.step[b][i].c = c;
     }
     if (b == 0)
         P.n_in = (uint32_t)ins.size();
@@ -256,7 +262,7 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
         P.rows = p0->h;
         P.row_units = row_units;
     }
-    hipError_t e = launch_chain(P, batch, bc.has_pow, c.max_blocks, c.chain_unroll, c.stream);
+    hipError_t e = launch_chain(P, batch, bc.mode, c.max_blocks, c.chain_unroll, c.stream);
     if (e != hipSuccess) {
         for (auto *o : outs) plane_release(o);
         return hip_fail(e, "launch_chain");
