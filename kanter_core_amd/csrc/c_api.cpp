@@ -59,6 +59,7 @@ int kc_init(int device_ordinal)
     }
     if (const char *rm = std::getenv("KC_RESIZE_MODE")) c.resize_mode = std::atoi(rm);
     if (const char *rt = std::getenv("KC_RESIZE_TILE_H")) c.resize_tile_h = std::atoi(rt);
+    if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
     if (const char *cu = std::getenv("KC_CHAIN_UNROLL")) {
         int v = std::atoi(cu);
         if (v == 1 || v == 2 || v == 4) c.chain_unroll = v;

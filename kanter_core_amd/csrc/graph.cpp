@@ -819,6 +819,7 @@ int kc_live_graph::ensure_clean(uint32_t id, int guard)
 int kc_live_graph::await_clean(uint32_t id)
 {
     if (!g.find(id)) return KC_ERR_INVALID_NODE_ID;
+    ResizeMemoScope memo;
     if (auto_update) KC_TRY(update());
     KC_TRY(ensure_clean(id, 0));
     // Clean means computed: whatever the node still holds is brought into HBM now.
@@ -829,6 +830,7 @@ int kc_live_graph::await_clean(uint32_t id)
 
 int kc_live_graph::update()
 {
+    ResizeMemoScope memo;
     // engine.rs:131-167
     std::vector<uint32_t> requested;
     for (auto &kv : node_state) {

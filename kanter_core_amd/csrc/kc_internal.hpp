@@ -92,8 +92,8 @@ inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t nrp, uint
     return ((size_t)nrp * ncp + (size_t)tile_h * ncp + 2u * tile_h + (size_t)tile_h * v_stride) * sizeof(float);
 }
 hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
-                             uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
-                             uint32_t nrp, hipStream_t s);
+                             uint32_t dh, TapsDev v, TapsDev h, uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h,
+                             uint32_t ncp, uint32_t nrp, hipStream_t s);
 hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, float *nx, float *ny,
                                    float *nz, uint32_t opitch, hipStream_t s);
 hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,

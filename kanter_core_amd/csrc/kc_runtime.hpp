@@ -56,7 +56,8 @@ struct Chain {
 struct TapsHost {
     std::vector<uint32_t> left, count;
     std::vector<float> w;
-    uint32_t stride = 1;
+    uint32_t stride = 1;     // max taps of any output index
+    uint32_t min_count = 1;  // min taps of any output index
 };
 
 struct TapsEntry {
@@ -76,10 +77,22 @@ struct Context {
     int max_blocks = 4096;
     int chain_unroll = 0;  // float4 per thread per decode in the chain kernel; 0 = heuristic (KC_CHAIN_UNROLL)
     int resize_mode = 0;  // 0 auto (LDS-tiled single pass when it fits), 3 two passes through HBM only (KC_RESIZE_MODE)
+    int resize_tile_w = 0;  // > 0: force this tile width (KC_RESIZE_TILE_W, tuning only)
     int resize_tile_h = 0;  // > 0: force this tile height for 256-wide tiles (KC_RESIZE_TILE_H, tuning only)
     std::multimap<size_t, void *> free_blocks;
     uint64_t bytes_in_use = 0, bytes_cached = 0, launches = 0;
     std::map<std::tuple<uint32_t, uint32_t, int>, TapsEntry> taps;
+    // Within one graph evaluation the same plane resized to the same size with the same filter is
+    // computed once (the reference resamples it per consuming node, src/shared.rs:152-207; planes
+    // are immutable, so the result is identical).  Both planes are retained while memoised.
+    int memo_depth = 0;
+    std::map<std::tuple<kc_plane *, uint32_t, uint32_t, int>, kc_plane *> resize_memo;
+};
+
+// RAII scope for the resize memo (nested Graph nodes share the outermost scope).
+struct ResizeMemoScope {
+    ResizeMemoScope();
+    ~ResizeMemoScope();
 };
 
 Context &ctx();

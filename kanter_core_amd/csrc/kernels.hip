@@ -384,7 +384,7 @@ hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *ds
 //           four results leave as one 16-byte store.
 // Same operands, same order, same roundings as the two-pass form: bit-identical output.
 // Algorithmic bytes per output pixel = 4 * (1 + in_px / out_px).
-template <int TAPS>  // max horizontal taps held in registers; 0 = any count, weights read per use
+template <int MINT, int MAXT>  // horizontal taps: MINT unconditional, up to MAXT in registers; MAXT = 0: any count
 __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict__ src, uint32_t spitch,
                                                          float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
                                                          uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
@@ -413,18 +413,23 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict
     const uint32_t cg = threadIdx.x % col_groups;
     const uint32_t rg = threadIdx.x / col_groups;
     const uint32_t ox = x0 + 4 * cg;
+    constexpr int NT = MAXT > 0 ? MAXT : 1;
     uint32_t hl[4], hn[4];
     const float *wh[4];
-    float wreg[4][TAPS > 0 ? TAPS : 1];
+    float wreg[4][NT];
+    bool live[4][NT];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const uint32_t x = min(ox + e, x1 - 1);
         hl[e] = H.left[x] - c0;
         hn[e] = H.count[x];
         wh[e] = H.w + (size_t)x * H.stride;
-        if constexpr (TAPS > 0) {
+        if constexpr (MAXT > 0) {
 #pragma unroll
-            for (int j = 0; j < TAPS; ++j) wreg[e][j] = (uint32_t)j < hn[e] ? wh[e][j] : 0.0f;
+            for (int j = 0; j < MAXT; ++j) {
+                live[e][j] = (uint32_t)j < hn[e];
+                wreg[e][j] = live[e][j] ? wh[e][j] : 0.0f;
+            }
         }
     }
 
@@ -456,26 +461,48 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict
     __syncthreads();
 
     if (ox >= x1) return;
-    for (uint32_t ty = rg; ty < th; ty += row_groups) {
+    auto out_row = [&](uint32_t ty, float (&res)[4]) {
         const float *row = tmp + ty * ncp;
-        float res[4];
+        if constexpr (MAXT > 0) {
+            // Taps are contiguous from hl[e]: one base address per output, constant offsets per tap
+            // (ds_read2).  A tap past the window reads the next floats of the LDS block -- always
+            // inside the allocation (the vertical tap table follows tmp) -- and is discarded below.
+            float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const float *pe[4] = { row + hl[0], row + hl[1], row + hl[2], row + hl[3] };
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = 0.0f;
-            if constexpr (TAPS > 0) {
-                t += row[hl[e]] * wreg[e][0];  // every window has at least one tap
+            for (int j = 0; j < MAXT; ++j) {
 #pragma unroll
-                for (int j = 1; j < TAPS; ++j)
-                    if ((uint32_t)j < hn[e]) t += row[hl[e] + j] * wreg[e][j];
-            } else {
-                for (uint32_t j = 0; j < hn[e]; ++j) t += row[hl[e] + j] * wh[e][j];
+                for (int e = 0; e < 4; ++e) {
+                    const float p = pe[e][j] * wreg[e][j];
+                    // a tap that does not exist contributes -0.0: t + (-0.0) == t for every t
+                    // (including +-0, +-inf, NaN), so the sum equals the reference's shorter sum
+                    t[e] += (j < MINT || live[e][j]) ? p : -0.0f;
+                }
             }
-            res[e] = clamp01_nan_passthrough(t);
-        }
-        float *o = dst + (size_t)(y0 + ty) * dpitch + ox;
-        if (ox + 3 < x1) {
-            *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[e] = clamp01_nan_passthrough(t[e]);
         } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = 0.0f;
+                for (uint32_t j = 0; j < hn[e]; ++j) t += row[hl[e] + j] * wh[e][j];
+                res[e] = clamp01_nan_passthrough(t);
+            }
+        }
+    };
+    if (ox + 3 < x1) {
+        // interior columns: one 16-byte store per row
+        for (uint32_t ty = rg; ty < th; ty += row_groups) {
+            float res[4];
+            out_row(ty, res);
+            *reinterpret_cast<float4 *>(dst + (size_t)(y0 + ty) * dpitch + ox) = make_float4(res[0], res[1], res[2], res[3]);
+        }
+    } else {
+        // the tile's last, partial quad
+        for (uint32_t ty = rg; ty < th; ty += row_groups) {
+            float res[4];
+            out_row(ty, res);
+            float *o = dst + (size_t)(y0 + ty) * dpitch + ox;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (ox + e < x1) o[e] = res[e];
@@ -483,20 +510,34 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict
     }
 }
 
+template <int MINT>
+static void launch_resize_lds_t(dim3 grid, size_t lds, hipStream_t s, uint32_t maxt, const float *src, uint32_t spitch,
+                                float *dst, uint32_t dpitch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
+                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp, uint32_t nrp)
+{
+#define KC_RESIZE_LAUNCH(MAXT) \
+    resize_lds_kernel<(MINT <= MAXT ? MINT : MAXT), MAXT><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp)
+    if (maxt <= 1) KC_RESIZE_LAUNCH(1);
+    else if (maxt == 2) KC_RESIZE_LAUNCH(2);
+    else if (maxt == 3) KC_RESIZE_LAUNCH(3);
+    else if (maxt == 4) KC_RESIZE_LAUNCH(4);
+    else if (maxt <= 6) KC_RESIZE_LAUNCH(6);
+    else resize_lds_kernel<0, 0><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+#undef KC_RESIZE_LAUNCH
+}
+
 hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
-                             uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
-                             uint32_t nrp, hipStream_t s)
+                             uint32_t dh, TapsDev v, TapsDev h, uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h,
+                             uint32_t ncp, uint32_t nrp, hipStream_t s)
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
     const size_t lds = resize_lds_bytes(tile_h, ncp, nrp, v.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h);
-    if (h.stride <= 2)
-        resize_lds_kernel<2><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
-    else if (h.stride <= 4)
-        resize_lds_kernel<4><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    if (h_min_count >= 2)
+        launch_resize_lds_t<2>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
     else
-        resize_lds_kernel<0><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+        launch_resize_lds_t<1>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
     return hipGetLastError();
 }
 

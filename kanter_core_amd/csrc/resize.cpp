@@ -83,6 +83,7 @@ int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
         t.left[o] = (uint32_t)l;
         t.count[o] = (uint32_t)(r - l);
         if (t.count[o] > t.stride) t.stride = t.count[o];
+        if (o == 0 || t.count[o] < t.min_count) t.min_count = t.count[o];
     }
     t.w.assign((size_t)out_n * t.stride, 0.0f);
     for (uint32_t o = 0; o < out_n; ++o) {
@@ -144,7 +145,54 @@ static uint32_t tile_ncap(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
     return cap;
 }
 
+ResizeMemoScope::ResizeMemoScope()
+{
+    Context &c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    c.memo_depth++;
+}
+
+ResizeMemoScope::~ResizeMemoScope()
+{
+    Context &c = ctx();
+    std::lock_guard<std::recursive_mutex> lk(c.mu);
+    if (--c.memo_depth == 0) {
+        for (auto &kv : c.resize_memo) {
+            plane_release(std::get<0>(kv.first));
+            plane_release(kv.second);
+        }
+        c.resize_memo.clear();
+    }
+}
+
+static int resize_plane_uncached(kc_plane *src, kc_size size, int filter, kc_plane **out);
+
 static int resize_plane(kc_plane *src, kc_size size, int filter, kc_plane **out)
+{
+    Context &c = ctx();
+    if (c.memo_depth == 0) return resize_plane_uncached(src, size, filter, out);
+    auto key = std::make_tuple(src, size.width, size.height, filter);
+    auto it = c.resize_memo.find(key);
+    if (it != c.resize_memo.end()) {
+        plane_retain(it->second);
+        *out = it->second;
+        return KC_OK;
+    }
+    KC_TRY(resize_plane_uncached(src, size, filter, out));
+    if (c.resize_memo.size() >= 32) {  // bound the HBM a long evaluation can pin
+        for (auto &kv : c.resize_memo) {
+            plane_release(std::get<0>(kv.first));
+            plane_release(kv.second);
+        }
+        c.resize_memo.clear();
+    }
+    plane_retain(src);
+    plane_retain(*out);
+    c.resize_memo.emplace(key, *out);
+    return KC_OK;
+}
+
+static int resize_plane_uncached(kc_plane *src, kc_size size, int filter, kc_plane **out)
 {
     Context &c = ctx();
     // A 1x1 source has a single tap whose normalised weight is w/w = 1, in both passes:
@@ -171,17 +219,17 @@ static int resize_plane(kc_plane *src, kc_size size, int filter, kc_plane **out)
     // LDS-tiled single pass when one tile's source neighbourhood + vertical-pass intermediate fit
     // in 64 KiB of LDS (every up-sample, moderate down-samples); otherwise (very wide windows) two
     // passes through an HBM intermediate.  Bigger tiles first: they amortise the table fetches.
-    static const uint32_t tiles[][2] = { { 256, 64 }, { 256, 32 }, { 256, 16 }, { 128, 16 }, { 64, 16 },
-                                         { 64, 8 },   { 32, 8 },   { 16, 8 },   { 16, 4 } };
+    static const uint32_t tiles[][2] = { { 1024, 16 }, { 512, 16 }, { 256, 64 }, { 256, 32 }, { 256, 16 }, { 128, 16 },
+                                         { 64, 16 },   { 64, 8 },   { 32, 8 },   { 16, 8 },   { 16, 4 } };
     bool done = false;
     if (c.resize_mode != 3) {
         for (auto &tl : tiles) {
-            if (c.resize_tile_h > 0 && tl[1] != (uint32_t)c.resize_tile_h && tl[0] == 256) continue;
+            if (c.resize_tile_w > 0 && (tl[0] != (uint32_t)c.resize_tile_w || (c.resize_tile_h > 0 && tl[1] != (uint32_t)c.resize_tile_h)) && tl[0] >= 256) continue;
             const uint32_t ncp = tile_ncap(th->host, size.width, tl[0]) | 1u;  // odd pitch spreads LDS banks
             const uint32_t nrp = tile_ncap(tv->host, size.height, tl[1]);
             if (resize_lds_bytes(tl[1], ncp, nrp, tv->dev.stride) <= 64 * 1024) {
                 hipError_t e = launch_resize_lds(src->dptr, spitch, dst->dptr, dpitch, size.width, size.height, tv->dev,
-                                                 th->dev, tl[0], tl[1], ncp, nrp, c.stream);
+                                                 th->dev, th->host.min_count, tl[0], tl[1], ncp, nrp, c.stream);
                 if (e != hipSuccess) {
                     plane_release(dst);
                     return hip_fail(e, "launch_resize_lds");
