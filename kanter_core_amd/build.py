@@ -21,6 +21,10 @@ HEADERS = ["kc_internal.hpp", "kc_runtime.hpp", os.path.join("..", "..", "includ
 # fuse a*b+c and divide exactly); see INTEGRATION.md.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-fast-math",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-result"]
+# Device code only: leave wave-uniform branches (the chain kernel's scalar step dispatch) as plain
+# scalar branches instead of structurizing them -- removes the per-arm "Flow" blocks and register
+# copies (90 -> 58 VGPRs, ~20 -> ~13 scalar instructions per step; profiles/r01_chain_unroll.md).
+DEVICE_FLAGS = ["-mllvm", "-structurizecfg-skip-uniform-regions=1"]
 
 
 def _hipcc():
@@ -48,7 +52,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + (DEVICE_FLAGS + ["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
             jobs.append(cmd)
 
     def run(cmd):

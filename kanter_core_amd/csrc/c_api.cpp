@@ -62,7 +62,7 @@ int kc_init(int device_ordinal)
     if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
     if (const char *cu = std::getenv("KC_CHAIN_UNROLL")) {
         int v = std::atoi(cu);
-        if (v == 1 || v == 2 || v == 4) c.chain_unroll = v;
+        if (v == 1 || v == 2 || v == 4 || v == 8) c.chain_unroll = v;
     }
     c.inited = true;
     return KC_OK;

@@ -280,6 +280,7 @@ hipError_t launch_chain(const ChainProgram &p, int batch, int mode, int max_bloc
     switch (unroll) {
     case 1: return launch_chain_u<1, 0>(p, batch, total, max_blocks, s);
     case 2: return launch_chain_u<2, 0>(p, batch, total, max_blocks, s);
+    case 8: return launch_chain_u<8, 0>(p, batch, total, max_blocks, s);
     default: return launch_chain_u<4, 0>(p, batch, total, max_blocks, s);
     }
 }
@@ -522,6 +523,7 @@ static void launch_resize_lds_t(dim3 grid, size_t lds, hipStream_t s, uint32_t m
     else if (maxt == 3) KC_RESIZE_LAUNCH(3);
     else if (maxt == 4) KC_RESIZE_LAUNCH(4);
     else if (maxt <= 6) KC_RESIZE_LAUNCH(6);
+    else if (maxt <= 8) KC_RESIZE_LAUNCH(8);
     else resize_lds_kernel<0, 0><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
 #undef KC_RESIZE_LAUNCH
 }
@@ -554,15 +556,24 @@ static __device__ __forceinline__ void vnorm3(float x, float y, float z, float &
     oz = z / n;
 }
 
+// 0.0f / n for a norm n that is never zero here (n >= 1/width > 0): +0 unless n is NaN.  Saves two
+// of the nine IEEE divisions per pixel; this kernel is bound by divide / sqrt issue, not by HBM.
+static __device__ __forceinline__ float zero_over(float n) { return n != n ? n : 0.0f; }
+
 static __device__ __forceinline__ void h2n_px(float px, float up, float left, float pdx, float pdy, float &r, float &g,
                                               float &b)
 {
-    float tx, ty, tz, bx, by, bz, nx, ny, nz;
-    vnorm3(pdx, 0.0f, px - left, tx, ty, tz);
-    vnorm3(0.0f, pdy, up - px, bx, by, bz);
+    // tangent = (pdx, 0, px - left) / |.|, bitangent = (0, pdy, up - px) / |.|;
+    // |v| = sqrt((x*x + y*y) + z*z) and x*x + 0*0 == x*x exactly
+    const float tz0 = px - left, bz0 = up - px;
+    const float n1 = sqrtf(pdx * pdx + tz0 * tz0);
+    const float n2 = sqrtf(pdy * pdy + bz0 * bz0);
+    const float tx = pdx / n1, ty = zero_over(n1), tz = tz0 / n1;
+    const float bx = zero_over(n2), by = pdy / n2, bz = bz0 / n2;
     const float cx = ty * bz - tz * by;
     const float cy = tz * bx - tx * bz;
     const float cz = tx * by - ty * bx;
+    float nx, ny, nz;
     vnorm3(cx, cy, cz, nx, ny, nz);
     r = nx * 0.5f + 0.5f;
     g = ny * 0.5f + 0.5f;
