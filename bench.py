@@ -16,6 +16,8 @@ Other workloads (parity-tested configs of BASELINE.json, reported in DESIGN.md, 
     --workload mix1           config #1: one Mix(Add) node, two 4096^2 f32x4 inputs
     --workload resize_blend   config #2: 512^2 -> 4096^2 Triangle resize + 3-node blend chain
     --workload chain32 --size 8192   config #3 at its full size
+    --workload chain32_rows --size 8192   config #3 split by row bands over the ranks (strong scaling:
+                              a pointwise graph needs no exchange, every rank owns rows [y0, y1) of every plane)
     --workload fanin          config #4: 8 independent 16-node subgraphs, results gathered to rank 0
                               over RCCL and summed by a 7-node Mix(Add) tree
 """
@@ -64,7 +66,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="chain32", choices=["chain32", "mix1", "resize_blend", "fanin"])
+    ap.add_argument("--workload", default="chain32", choices=["chain32", "chain32_rows", "mix1", "resize_blend", "fanin"])
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,8 +106,20 @@ def main():
     # ------------------------------------------------------------------ workloads
     # each returns: step(), node_px per step (this rank), algorithmic HBM bytes per step, description
     host_a = host_b = None
+    rows = S
+    if args.workload == "chain32_rows":
+        # strong scaling of ONE graph: this rank owns a row band of every plane
+        y0, y1 = multi_gpu.row_bands(S, world)[rank]
+        rows = y1 - y0
+        full = lambda seed: [splitmix_plane(seed, c, S, S)[y0:y1].copy() for c in range(4)]  # noqa: E731
+        host_a, host_b = full(SEED_A), full(SEED_B)
+        args.workload = "chain32"
+        band_note = " (row band %d:%d of %d, rank %d/%d)" % (y0, y1, S, rank, world)
+    else:
+        band_note = ""
     if args.workload == "chain32":
-        host_a, host_b = synth(SEED_A, S), synth(SEED_B, S)
+        if host_a is None:
+            host_a, host_b = synth(SEED_A, S), synth(SEED_B, S)
         img_a, img_b = kc.SlotImage.from_planes(host_a), kc.SlotImage.from_planes(host_b)
 
         def make(use_cache):
@@ -122,13 +136,13 @@ def main():
             lg.connect(na, first, 0, 0)  # re-plugging the input dirties the whole chain (live_graph.rs:488-511)
             lg.await_clean(last)
 
-        node_px = float(N) * S * S
+        node_px = float(N) * S * rows
         # fused: R,G,B of A and B read once (24 B/px), R,G,B of the result written once (12 B/px);
         # alpha is a constant plane (0 B).  DESIGN.md "Kernels".
-        alg_bytes = 36.0 * S * S
+        alg_bytes = 36.0 * S * rows
         kernel = "chain_kernel<2,4,0>"
         desc = ("%d-node linear Mix graph (Add/Multiply alternating with invert = Mix(Subtract)(1, x)), "
-                "%dx%d f32x4 per GPU, SURVEY 8(d) config #3" % (N, S, S))
+                "%dx%d f32x4 per GPU, SURVEY 8(d) config #3%s" % (N, S, rows, band_note))
     elif args.workload == "mix1":
         host_a, host_b = synth(SEED_A, S), synth(SEED_B, S)
         img_a, img_b = kc.SlotImage.from_planes(host_a), kc.SlotImage.from_planes(host_b)
@@ -285,7 +299,7 @@ def main():
         except Exception:
             traffic = None
 
-    headline = args.workload == "chain32" and S == 4096 and N == 32
+    headline = args.workload == "chain32" and S == 4096 and N == 32 and not band_note
     out = {
         "metric": "node-Mpix/s on 4096x4096 f32x4, 32-node graph" if headline else "node-Mpix/s, %s" % args.workload,
         "value": round(value, 1),
@@ -295,7 +309,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak" if args.workload != "fanin" else "strong",
+        "scaling": "strong" if (args.workload == "fanin" or band_note) else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -320,7 +334,7 @@ def main():
         k2 = max(5, args.steps // 10)
         wall_u, dev_u, launches_u = timed(lambda: step(gu), k2, 2, sync_ranks=False)
         # unfused algorithmic bytes: two-plane Mix 36 B/px, invert (scalar left) 24 B/px
-        unf_bytes = ((N + 1) // 2 * 36.0 + N // 2 * 24.0) * S * S
+        unf_bytes = ((N + 1) // 2 * 36.0 + N // 2 * 24.0) * S * rows
         out["unfused"] = {
             "value": round(node_px * k2 / wall_u / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(wall_u / k2 * 1e3, 4),
             "launches_per_step": launches_u / k2, "achieved_GBps": round(unf_bytes * k2 / dev_u / 1e9, 1),
@@ -357,7 +371,7 @@ def main():
         # parity of the timed workload against the oracle, on the same inputs
         got = g[0].slot_data(g[3], 0).image.planes()
         mism = int(sum((x.view(np.uint32) != y.view(np.uint32)).sum() for x, y in zip(got, ref)))
-        out["parity"] = {"checked_pixels": S * S * 4, "bit_mismatches": mism}
+        out["parity"] = {"checked_pixels": S * rows * 4, "bit_mismatches": mism}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -1,0 +1,123 @@
+"""Lazy-chain corner cases of the fused Mix kernel: program cuts (more than 64 steps, more than 4
+distinct input planes), diamonds (both Mix operands lazy), the same plane on both sides, type
+changes in the middle of a chain, constant folding, and plane-pool accounting.  Every case is
+checked bit for bit against the oracle evaluated node by node."""
+import numpy as np
+import pytest
+
+from util import SEED_A, SEED_B, assert_planes, bit_equal, splitmix_plane
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kc():
+    import kanter_core_amd as kc
+    kc.init(0)
+    return kc
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as orc
+    return orc
+
+
+def gray(kc, p):
+    return kc.SlotImage.from_planes([p])
+
+
+def test_long_chain_is_cut_at_64_steps_and_4_planes(kc, orc):
+    h, w = 24, 40
+    planes = [splitmix_plane(SEED_A + i, 0, h, w) * np.float32(0.5) + np.float32(0.25) for i in range(7)]
+    imgs = [gray(kc, p) for p in planes]
+    ops = ["Add", "Multiply", "Subtract", "Multiply", "Add"]
+    x, want = imgs[0], planes[0]
+    l0 = kc.stats()["kernel_launches"]
+    for i in range(150):
+        k = 1 + (i * 5 + i // 7) % 6          # walks over 6 other planes: forces > 4 distinct inputs
+        op = ops[i % len(ops)]
+        if i % 3 == 0:                          # operand on the left: x = planes[k] op x
+            x = kc.mix_process(imgs[k], x, kc.MixType.parse(op))
+            want = orc.mix_plane(op, planes[k], want)
+        else:
+            x = kc.mix_process(x, imgs[k], kc.MixType.parse(op))
+            want = orc.mix_plane(op, want, planes[k])
+    got = x.planes()
+    launches = kc.stats()["kernel_launches"] - l0
+    assert_planes(got, [want], what="150-step chain")
+    assert 3 <= launches <= 150 // 3, launches   # cut every ~3-4 steps here (each restart spends one of the 4 input slots)
+
+
+def test_diamond_both_operands_lazy(kc, orc):
+    h, w = 33, 65
+    a, b = splitmix_plane(SEED_A, 0, h, w) + np.float32(0.5), splitmix_plane(SEED_B, 0, h, w) + np.float32(0.5)
+    A, B = gray(kc, a), gray(kc, b)
+    x = kc.mix_process(A, B, kc.MixType.Add)            # lazy
+    y1 = kc.mix_process(x, A, kc.MixType.Multiply)      # lazy, extends x
+    y2 = kc.mix_process(x, B, kc.MixType.Subtract)      # lazy, extends x again (x is recomputed, never stored)
+    z = kc.mix_process(y1, y2, kc.MixType.Divide)       # lazy x lazy
+    xo = orc.mix_plane("Add", a, b)
+    want = orc.mix_plane("Divide", orc.mix_plane("Multiply", xo, a), orc.mix_plane("Subtract", xo, b))
+    assert_planes(z.planes(), [want], what="diamond")
+    # the intermediates are still individually observable afterwards
+    assert_planes(x.planes(), [xo])
+    assert_planes(y2.planes(), [orc.mix_plane("Subtract", xo, b)])
+
+
+def test_same_plane_on_both_sides_and_self_power(kc, orc):
+    h, w = 16, 16
+    a = splitmix_plane(SEED_A, 1, h, w)
+    A = gray(kc, a)
+    assert_planes(kc.mix_process(A, A, kc.MixType.Multiply).planes(), [orc.mix_plane("Multiply", a, a)])
+    x = kc.mix_process(A, A, kc.MixType.Add)
+    xx = kc.mix_process(x, x, kc.MixType.Subtract)     # lazy with itself
+    assert_planes(xx.planes(), [orc.mix_plane("Subtract", orc.mix_plane("Add", a, a), orc.mix_plane("Add", a, a))])
+
+
+def test_type_change_mid_chain_and_alpha(kc, orc):
+    h, w = 20, 28
+    a = [splitmix_plane(SEED_A, c, h, w) for c in range(4)]
+    b = [splitmix_plane(SEED_B, c, h, w) for c in range(4)]
+    g = splitmix_plane(SEED_B, 5, h, w)
+    A, B, G = kc.SlotImage.from_planes(a), kc.SlotImage.from_planes(b), gray(kc, g)
+    x = kc.mix_process(A, B, kc.MixType.Multiply)                 # rgba, lazy
+    y = kc.mix_process(G, x, kc.MixType.Add)                      # gray left: x averaged ((r+g)+b)/3, lazy chains merge
+    z = kc.mix_process(y, x, kc.MixType.Subtract)                 # gray
+    r = kc.mix_process(x, z, kc.MixType.Add)                      # rgba left, gray right broadcast
+    xo = [orc.mix_plane("Multiply", a[c], b[c]) for c in range(3)]
+    xg = orc.rgba_to_gray(*xo)
+    yo = orc.mix_plane("Add", g, xg)
+    zo = orc.mix_plane("Subtract", yo, xg)
+    want = [orc.mix_plane("Add", xo[c], zo) for c in range(3)] + [np.ones_like(g)]
+    assert r.is_rgba()
+    assert_planes(r.planes(), want, what="type change")
+
+
+def test_constant_folding_matches_device_arithmetic(kc, orc):
+    one = np.ones((1, 1), np.float32)
+    for op in ("Add", "Subtract", "Multiply", "Divide", "Pow"):
+        for lv, rv in ((0.33, 0.66), (1.0, 3.0), (-2.0, 0.5), (0.0, 0.0), (7.5, -2.0)):
+            img = kc.mix_process(kc.value_process(lv), kc.value_process(rv), kc.MixType.parse(op))
+            want = orc.mix_plane(op, one * np.float32(lv), one * np.float32(rv))
+            got = img.planes()[0]
+            assert img.size() == (1, 1)
+            assert bit_equal(got, want) or (op == "Pow" and abs(int(got.view(np.int32)[0, 0]) - int(want.view(np.int32)[0, 0])) <= 1), (op, lv, rv)
+
+
+def test_pool_returns_to_baseline(kc):
+    import gc
+    gc.collect()
+    kc.sync()
+    base = kc.stats()["bytes_in_use"]
+    h, w = 128, 192
+    a = [splitmix_plane(SEED_A, c, h, w) for c in range(4)]
+    A = kc.SlotImage.from_planes(a)
+    assert kc.stats()["bytes_in_use"] == base + 4 * h * w * 4          # 192 * 4 B is already a multiple of 256
+    x = kc.mix_process(A, A, kc.MixType.Add)
+    assert kc.stats()["bytes_in_use"] == base + 4 * h * w * 4          # lazy: no bytes yet
+    x.planes()
+    assert kc.stats()["bytes_in_use"] == base + 7 * h * w * 4          # R, G, B materialised; alpha stays constant
+    del x, A
+    gc.collect()
+    assert kc.stats()["bytes_in_use"] == base
