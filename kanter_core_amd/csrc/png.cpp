@@ -76,7 +76,7 @@ int png_read(const std::string &path, std::vector<uint8_t> &px, uint32_t &w, uin
     case 6: chans = 4; break;
     }
     const bool depth_ok = depth == 8 || (color == 3 && (depth == 1 || depth == 2 || depth == 4));
-    if (!have_ihdr || chans == 0 || !depth_ok || interlace != 0 || w == 0 || h == 0) {
+    if (!have_ihdr || chans == 0 || !depth_ok || interlace != 0 || w == 0 || h == 0 || w > 65535 || h > 65535) {
         set_error(path + ": unsupported PNG variant");
         return KC_ERR_IMAGE;
     }

@@ -121,3 +121,49 @@ def test_pool_returns_to_baseline(kc):
     del x, A
     gc.collect()
     assert kc.stats()["bytes_in_use"] == base
+
+
+def test_entry_points_are_thread_safe(kc, orc):
+    """The reference runs process_node on one OS thread per ready node (src/engine.rs:288): the
+    C ABI must tolerate concurrent callers.  8 threads build and evaluate their own graphs at once."""
+    import threading
+    h, w = 64, 96
+    errors, results = [], {}
+
+    def work(tid):
+        try:
+            a = [splitmix_plane(SEED_A + tid, c, h, w) for c in range(4)]
+            b = [splitmix_plane(SEED_B + tid, c, h, w) for c in range(4)]
+            tp = kc.TextureProcessor.new()
+            for rep in range(5):
+                lg = tp.new_live_graph()
+                lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(a)), 0)
+                lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(b)), 1)
+                na = lg.add_node(kc.Node.new(kc.NodeType.Embed(0)))
+                nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(1)))
+                prev = na
+                for i in range(6):
+                    n = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add if i & 1 else kc.MixType.Multiply)))
+                    lg.connect(prev, n, 0, 0)
+                    lg.connect(nb, n, 0, 1)
+                    prev = n
+                small = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)).with_resize_policy(
+                    kc.ResizePolicy.SpecificSize(kc.Size(w // 2, h // 2))))
+                lg.connect(prev, small, 0, 0)
+                results[(tid, rep)] = lg.await_clean(small).slot_data(small, 0).image.planes()
+            want = [p.copy() for p in a[:3]]
+            for i in range(6):
+                want = [orc.mix_plane("Add" if i & 1 else "Multiply", want[c], b[c]) for c in range(3)]
+            want = [orc.resize_plane(p, w // 2, h // 2, "Triangle") for p in want + [np.ones((h, w), np.float32)]]
+            want = [orc.mix_plane("Add", p, np.zeros_like(p)) for p in want[:3]] + [np.ones((h // 2, w // 2), np.float32)]
+            for rep in range(5):
+                assert_planes(results[(tid, rep)], want, what="thread %d rep %d" % (tid, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
