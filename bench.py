@@ -181,11 +181,10 @@ def main():
             lg.await_clean(n3)
 
         node_px = 3.0 * S * S
-        # B is resampled once per evaluation (4 planes; identical resizes are memoised, the reference
-        # repeats it per consuming node): 4 B written + source read per plane; the fused 3-node chain
-        # reads A (3 planes) and B-up (3 planes) once and writes 3 planes.
-        alg_bytes = 4 * 4.0 * (S * S + s_small * s_small) + (3 + 3 + 3) * 4.0 * S * S
-        kernel = "resize_lds_kernel<2,3> x4 + chain_kernel<2,4,0>"
+        # fused: the resampled B never exists in HBM.  One launch reads R,G,B of A (12 B/px) and of the
+        # small B source, resamples B inside the kernel and writes R,G,B of the result (12 B/px).
+        alg_bytes = (3 + 3) * 4.0 * S * S + 3 * 4.0 * s_small * s_small
+        kernel = "resize_chain_kernel<2,3>"
         desc = "B %d^2 -> %d^2 Triangle resize + 3-node blend chain, BASELINE config #2" % (s_small, S)
     else:  # fanin
         n_branches, sub_nodes = 8, 16

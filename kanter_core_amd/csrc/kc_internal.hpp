@@ -56,6 +56,9 @@ struct ChainProgram {
     float *out[KC_CHAIN_MAX_BATCH];
     uint32_t out_pitch[KC_CHAIN_MAX_BATCH];
     float start_c[KC_CHAIN_MAX_BATCH];
+    // resize_chain_kernel only: the source plane of the resampled operand (input slot n_in - 1)
+    const float *samp_src[KC_CHAIN_MAX_BATCH];
+    uint32_t samp_pitch[KC_CHAIN_MAX_BATCH];  // in floats
     // One 8-byte record per step and channel so the decode is a single scalar (SMEM) load; one
     // spare record lets the loop prefetch step i + 1 unconditionally.
     ChainStepRec step[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_OPS + 1];
@@ -94,6 +97,9 @@ inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t nrp, uint
 hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
                              uint32_t dh, TapsDev v, TapsDev h, uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h,
                              uint32_t ncp, uint32_t nrp, hipStream_t s);
+// Fused resample + chain: input slot n_in - 1 of the program is produced by the resampler.
+hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
+                               uint32_t tile_w, uint32_t tile_h, uint32_t ncp, uint32_t nrp, hipStream_t s);
 hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, float *nx, float *ny,
                                    float *nz, uint32_t opitch, hipStream_t s);
 hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,

@@ -16,9 +16,11 @@ struct Chain;
 
 // One channel.  MEM: pitched f32 in HBM.  CONST: broadcast scalar (what the reference holds as
 // vec![v; n]).  LAZY: a pointwise Mix chain that has not been run yet; forcing it launches the
-// fused chain kernel and turns the plane into MEM.
+// fused chain kernel and turns the plane into MEM.  RESIZE: `rz_src` resampled to w x h with
+// `rz_filter`, not run yet: a Mix chain that consumes it resamples inside its own kernel
+// (resize_chain_kernel), anything else forces it through the plain resize kernel.
 struct kc_plane {
-    enum Kind { MEM = 0, CONST = 1, LAZY = 2 };
+    enum Kind { MEM = 0, CONST = 1, LAZY = 2, RESIZE = 3 };
     std::atomic<int> refs{ 1 };
     uint32_t w = 0, h = 0;
     Kind kind = MEM;
@@ -28,6 +30,8 @@ struct kc_plane {
     bool owned = false;
     float cval = 0.0f;
     kc::Chain *chain = nullptr;
+    kc_plane *rz_src = nullptr;  // retained; MEM
+    int rz_filter = 0;
 };
 
 // SlotImage, src/slot_image.rs:15-19
@@ -147,6 +151,11 @@ int height_to_normal_process(kc_image *in, kc_image **out);
 // ---- resize (resize.cpp) ----
 int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t);
 int resize_image(kc_image *src, kc_size size, int filter, kc_image **out);
+int resize_force(kc_plane *p);  // RESIZE -> MEM through the plain resize kernel
+// Runs a chain whose operands include ONE resampled plane per channel inside the resize kernel
+// (phase 2 feeds the chain program).  *launched = false when the case is not eligible (taps not
+// in registers, tile does not fit LDS, program too long): the caller forces the RESIZE planes.
+int chain_resize_launch(const ChainProgram &P, int batch, int mode, kc_plane *const *sampled, bool *launched);
 
 // ---- png / json (png.cpp, json.cpp) ----
 int png_read(const std::string &path, std::vector<uint8_t> &px, uint32_t &w, uint32_t &h, int &channels);

@@ -377,75 +377,86 @@ hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *ds
 
 // Single-pass LDS-tiled form: each workgroup owns a tile_h x tile_w output tile.
 //   stage   the tile's source neighbourhood (nr x nc floats, coalesced rows) and the vertical tap
-//           table of its rows go to LDS once -- the only HBM reads of the kernel;
+//           table of its rows go to LDS once -- the only HBM reads of the resampler;
 //   phase 1 vertical pass LDS -> LDS: the intermediate the two-pass form would write to HBM
 //           (tile_h x nc floats) never leaves the CU;
 //   phase 2 horizontal pass out of LDS: every thread owns 4 consecutive output columns for the
-//           whole tile, so its tap windows and (TAPS > 0) its weights sit in registers and the
-//           four results leave as one 16-byte store.
+//           whole tile, so its tap windows and (MAXT > 0) its weights sit in registers and the
+//           four results leave as one 16-byte store -- or, in resize_chain_kernel, feed the Mix
+//           chain that consumes the resampled plane without ever being written.
 // Same operands, same order, same roundings as the two-pass form: bit-identical output.
 // Algorithmic bytes per output pixel = 4 * (1 + in_px / out_px).
-template <int MINT, int MAXT>  // horizontal taps: MINT unconditional, up to MAXT in registers; MAXT = 0: any count
-__global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict__ src, uint32_t spitch,
-                                                         float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
-                                                         uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
-                                                         uint32_t tile_h, uint32_t ncp, uint32_t nrp)
+struct ResizeTile {
+    uint32_t x0, y0, x1, y1, th, c0, nc;
+    const float *tmp;  // tile_h x ncp vertical-pass intermediate in LDS
+};
+
+template <int MAXT>
+struct ResizeCols {  // the 4 output columns a thread owns
+    static constexpr int NT = MAXT > 0 ? MAXT : 1;
+    uint32_t hl[4], hn[4];
+    const float *wh[4];
+    float wreg[4][NT];
+    bool live[4][NT];
+};
+
+template <int MAXT>
+static __device__ __forceinline__ void resize_load_cols(ResizeCols<MAXT> &C, const TapsDev &H, uint32_t ox, uint32_t x1,
+                                                        uint32_t c0)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t x = min(ox + e, x1 - 1);
+        C.hl[e] = H.left[x] - c0;
+        C.hn[e] = H.count[x];
+        C.wh[e] = H.w + (size_t)x * H.stride;
+        if constexpr (MAXT > 0) {
+#pragma unroll
+            for (int j = 0; j < MAXT; ++j) {
+                C.live[e][j] = (uint32_t)j < C.hn[e];
+                C.wreg[e][j] = C.live[e][j] ? C.wh[e][j] : 0.0f;
+            }
+        }
+    }
+}
+
+// Staging + phase 1 for the workgroup's tile; ends with the barrier that publishes `tmp`.
+static __device__ __forceinline__ ResizeTile resize_tile_prologue(float *lds, const float *__restrict__ src,
+                                                                  uint32_t spitch, uint32_t dw, uint32_t dh,
+                                                                  const TapsDev &V, const TapsDev &H, uint32_t tile_w,
+                                                                  uint32_t tile_h, uint32_t ncp, uint32_t nrp)
+{
     float *srcT = lds;                          // nrp x ncp
     float *tmp = srcT + nrp * ncp;              // tile_h x ncp
     uint32_t *vl = reinterpret_cast<uint32_t *>(tmp + tile_h * ncp);
     uint32_t *vn = vl + tile_h;
     float *vw = reinterpret_cast<float *>(vn + tile_h);  // tile_h x V.stride
 
-    const uint32_t x0 = blockIdx.x * tile_w;
-    const uint32_t y0 = blockIdx.y * tile_h;
-    const uint32_t x1 = min(x0 + tile_w, dw);
-    const uint32_t y1 = min(y0 + tile_h, dh);
-    const uint32_t th = y1 - y0;
-    const uint32_t c0 = H.left[x0];
-    const uint32_t nc = H.left[x1 - 1] + H.count[x1 - 1] - c0;  // <= ncp (host-checked)
-    const uint32_t r0 = V.left[y0];
-    const uint32_t nr = V.left[y1 - 1] + V.count[y1 - 1] - r0;  // <= nrp (host-checked)
-
-    // this thread's 4 output columns (fetched first so the loads overlap the staging below)
-    const uint32_t col_groups = tile_w / 4;         // threads across one tile row
-    const uint32_t row_groups = 256u / col_groups;  // tile rows in flight
-    const uint32_t cg = threadIdx.x % col_groups;
-    const uint32_t rg = threadIdx.x / col_groups;
-    const uint32_t ox = x0 + 4 * cg;
-    constexpr int NT = MAXT > 0 ? MAXT : 1;
-    uint32_t hl[4], hn[4];
-    const float *wh[4];
-    float wreg[4][NT];
-    bool live[4][NT];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t x = min(ox + e, x1 - 1);
-        hl[e] = H.left[x] - c0;
-        hn[e] = H.count[x];
-        wh[e] = H.w + (size_t)x * H.stride;
-        if constexpr (MAXT > 0) {
-#pragma unroll
-            for (int j = 0; j < MAXT; ++j) {
-                live[e][j] = (uint32_t)j < hn[e];
-                wreg[e][j] = live[e][j] ? wh[e][j] : 0.0f;
-            }
-        }
-    }
+    ResizeTile T;
+    T.x0 = blockIdx.x * tile_w;
+    T.y0 = blockIdx.y * tile_h;
+    T.x1 = min(T.x0 + tile_w, dw);
+    T.y1 = min(T.y0 + tile_h, dh);
+    T.th = T.y1 - T.y0;
+    T.c0 = H.left[T.x0];
+    T.nc = H.left[T.x1 - 1] + H.count[T.x1 - 1] - T.c0;  // <= ncp (host-checked)
+    T.tmp = tmp;
+    const uint32_t r0 = V.left[T.y0];
+    const uint32_t nr = V.left[T.y1 - 1] + V.count[T.y1 - 1] - r0;  // <= nrp (host-checked)
+    const uint32_t nc = T.nc, th = T.th;
 
     for (uint32_t i = threadIdx.x; i < th; i += 256u) {
-        vl[i] = V.left[y0 + i] - r0;
-        vn[i] = V.count[y0 + i];
+        vl[i] = V.left[T.y0 + i] - r0;
+        vn[i] = V.count[T.y0 + i];
     }
-    for (uint32_t i = threadIdx.x; i < th * V.stride; i += 256u) vw[i] = V.w[(size_t)y0 * V.stride + i];
+    for (uint32_t i = threadIdx.x; i < th * V.stride; i += 256u) vw[i] = V.w[(size_t)T.y0 * V.stride + i];
     // i / nc by multiply-high: exact here because i < (nrp + tile_h) * ncp <= 2^14 (64 KiB of LDS)
     const uint32_t nc_magic = nc > 1 ? 0xFFFFFFFFu / nc + 1u : 0u;
     auto div_nc = [&](uint32_t i) { return nc > 1 ? __umulhi(i, nc_magic) : i; };
     for (uint32_t i = threadIdx.x; i < nr * nc; i += 256u) {
         const uint32_t r = div_nc(i);
         const uint32_t c = i - r * nc;
-        srcT[r * ncp + c] = src[(size_t)(r0 + r) * spitch + c0 + c];
+        srcT[r * ncp + c] = src[(size_t)(r0 + r) * spitch + T.c0 + c];
     }
     __syncthreads();
 
@@ -460,53 +471,129 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict
         tmp[ty * ncp + cc] = t;
     }
     __syncthreads();
+    return T;
+}
 
-    if (ox >= x1) return;
-    auto out_row = [&](uint32_t ty, float (&res)[4]) {
-        const float *row = tmp + ty * ncp;
-        if constexpr (MAXT > 0) {
-            // Taps are contiguous from hl[e]: one base address per output, constant offsets per tap
-            // (ds_read2).  A tap past the window reads the next floats of the LDS block -- always
-            // inside the allocation (the vertical tap table follows tmp) -- and is discarded below.
-            float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-            const float *pe[4] = { row + hl[0], row + hl[1], row + hl[2], row + hl[3] };
+// Horizontal pass for one tile row and this thread's 4 columns.
+template <int MINT, int MAXT>
+static __device__ __forceinline__ void resize_out_row(const ResizeCols<MAXT> &C, const float *row, float (&res)[4])
+{
+    if constexpr (MAXT > 0) {
+        // Taps are contiguous from hl[e]: one base address per output, constant offsets per tap
+        // (ds_read2).  A tap past the window reads the next floats of the LDS block -- always
+        // inside the allocation (the vertical tap table follows tmp) -- and is discarded below.
+        float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const float *pe[4] = { row + C.hl[0], row + C.hl[1], row + C.hl[2], row + C.hl[3] };
 #pragma unroll
-            for (int j = 0; j < MAXT; ++j) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float p = pe[e][j] * wreg[e][j];
-                    // a tap that does not exist contributes -0.0: t + (-0.0) == t for every t
-                    // (including +-0, +-inf, NaN), so the sum equals the reference's shorter sum
-                    t[e] += (j < MINT || live[e][j]) ? p : -0.0f;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) res[e] = clamp01_nan_passthrough(t[e]);
-        } else {
+        for (int j = 0; j < MAXT; ++j) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float t = 0.0f;
-                for (uint32_t j = 0; j < hn[e]; ++j) t += row[hl[e] + j] * wh[e][j];
-                res[e] = clamp01_nan_passthrough(t);
+                const float p = pe[e][j] * C.wreg[e][j];
+                // a tap that does not exist contributes -0.0: t + (-0.0) == t for every t
+                // (including +-0, +-inf, NaN), so the sum equals the reference's shorter sum
+                t[e] += (j < MINT || C.live[e][j]) ? p : -0.0f;
             }
         }
-    };
-    if (ox + 3 < x1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) res[e] = clamp01_nan_passthrough(t[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = 0.0f;
+            for (uint32_t j = 0; j < C.hn[e]; ++j) t += row[C.hl[e] + j] * C.wh[e][j];
+            res[e] = clamp01_nan_passthrough(t);
+        }
+    }
+}
+
+template <int MINT, int MAXT>  // horizontal taps: MINT unconditional, up to MAXT in registers; MAXT = 0: any count
+__global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict__ src, uint32_t spitch,
+                                                         float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
+                                                         uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
+                                                         uint32_t tile_h, uint32_t ncp, uint32_t nrp)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t col_groups = tile_w / 4;         // threads across one tile row
+    const uint32_t row_groups = 256u / col_groups;  // tile rows in flight
+    const uint32_t cg = threadIdx.x % col_groups;
+    const uint32_t rg = threadIdx.x / col_groups;
+    const uint32_t x0 = blockIdx.x * tile_w, x1 = min(x0 + tile_w, dw);
+    const uint32_t ox = x0 + 4 * cg;
+    // this thread's 4 output columns (fetched first so the loads overlap the staging)
+    ResizeCols<MAXT> C;
+    resize_load_cols<MAXT>(C, H, ox, x1, H.left[x0]);
+    const ResizeTile T = resize_tile_prologue(lds, src, spitch, dw, dh, V, H, tile_w, tile_h, ncp, nrp);
+    if (ox >= T.x1) return;
+    if (ox + 3 < T.x1) {
         // interior columns: one 16-byte store per row
-        for (uint32_t ty = rg; ty < th; ty += row_groups) {
+        for (uint32_t ty = rg; ty < T.th; ty += row_groups) {
             float res[4];
-            out_row(ty, res);
-            *reinterpret_cast<float4 *>(dst + (size_t)(y0 + ty) * dpitch + ox) = make_float4(res[0], res[1], res[2], res[3]);
+            resize_out_row<MINT, MAXT>(C, T.tmp + ty * ncp, res);
+            *reinterpret_cast<float4 *>(dst + (size_t)(T.y0 + ty) * dpitch + ox) = make_float4(res[0], res[1], res[2], res[3]);
         }
     } else {
         // the tile's last, partial quad
-        for (uint32_t ty = rg; ty < th; ty += row_groups) {
+        for (uint32_t ty = rg; ty < T.th; ty += row_groups) {
             float res[4];
-            out_row(ty, res);
-            float *o = dst + (size_t)(y0 + ty) * dpitch + ox;
+            resize_out_row<MINT, MAXT>(C, T.tmp + ty * ncp, res);
+            float *o = dst + (size_t)(T.y0 + ty) * dpitch + ox;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (ox + e < x1) o[e] = res[e];
+                if (ox + e < T.x1) o[e] = res[e];
+        }
+    }
+}
+
+// Fused resample + Mix chain: phase 2's four results are input slot K-1 of the chain program, the
+// other K-1 inputs are resident planes read with one 16-byte load each, and only the chain's
+// result is stored.  The resampled plane itself never exists in HBM: per output pixel the launch
+// moves 4 * (K - 1 + 1) bytes plus the (small) source tile instead of 4 * (1 + K + 1).
+// blockIdx.z = channel (each channel resamples its own source plane with the shared tap tables).
+template <int K, int MAXT>
+__global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P, uint32_t dw, uint32_t dh, TapsDev V,
+                                                           TapsDev H, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
+                                                           uint32_t nrp)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t b = blockIdx.z;
+    const uint32_t col_groups = tile_w / 4;
+    const uint32_t row_groups = 256u / col_groups;
+    const uint32_t cg = threadIdx.x % col_groups;
+    const uint32_t rg = threadIdx.x / col_groups;
+    const uint32_t x0 = blockIdx.x * tile_w, x1 = min(x0 + tile_w, dw);
+    const uint32_t ox = x0 + 4 * cg;
+    ResizeCols<MAXT> C;
+    resize_load_cols<MAXT>(C, H, ox, x1, H.left[x0]);
+    const ResizeTile T = resize_tile_prologue(lds, P.samp_src[b], P.samp_pitch[b], dw, dh, V, H, tile_w, tile_h, ncp, nrp);
+    if (ox >= T.x1) return;
+    const f4 *inp[K > 1 ? K - 1 : 1];
+    uint32_t ipitch[K > 1 ? K - 1 : 1];
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) {
+        inp[k] = reinterpret_cast<const f4 *>(P.in[b][k]);
+        ipitch[k] = P.in_pitch[b][k];
+    }
+    float *outp = P.out[b];
+    const uint32_t opitch = P.out_pitch[b] * 4;  // floats
+    const bool full = ox + 3 < T.x1;
+    for (uint32_t ty = rg; ty < T.th; ty += row_groups) {
+        const uint32_t oy = T.y0 + ty;
+        f4 in[K][1];
+#pragma unroll
+        for (int k = 0; k < K - 1; ++k) in[k][0] = inp[k][oy * ipitch[k] + ox / 4];  // whole quad lies inside the pitch
+        float res[4];
+        resize_out_row<1, MAXT>(C, T.tmp + ty * ncp, res);
+        in[K - 1][0] = f4{ res[0], res[1], res[2], res[3] };
+        f4 acc[1];
+        chain_run<K, 1, 0>(P, b, in, acc);
+        float *o = outp + (size_t)oy * opitch + ox;
+        if (full) {
+            *reinterpret_cast<f4 *>(o) = acc[0];
+        } else {
+            const float r4[4] = { acc[0].x, acc[0].y, acc[0].z, acc[0].w };
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ox + e < T.x1) o[e] = r4[e];
         }
     }
 }
@@ -541,6 +628,38 @@ hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint
     else
         launch_resize_lds_t<1>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
     return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_resize_chain_k(const ChainProgram &p, dim3 grid, size_t lds, hipStream_t s, uint32_t dw,
+                                        uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
+                                        uint32_t nrp)
+{
+    switch (h.stride) {
+    case 1: resize_chain_kernel<K, 1><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp, nrp); break;
+    case 2: resize_chain_kernel<K, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp, nrp); break;
+    case 3: resize_chain_kernel<K, 3><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp, nrp); break;
+    case 4: resize_chain_kernel<K, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp, nrp); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
+                               uint32_t tile_w, uint32_t tile_h, uint32_t ncp, uint32_t nrp, hipStream_t s)
+{
+    if (dw == 0 || dh == 0) return hipSuccess;
+    if (batch < 1 || batch > KC_CHAIN_MAX_BATCH || p.n_ops < 1 || p.n_ops > KC_CHAIN_MAX_OPS) return hipErrorInvalidValue;
+    if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
+    const size_t lds = resize_lds_bytes(tile_h, ncp, nrp, v.stride);
+    dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h, batch);
+    switch (p.n_in) {
+    case 1: return launch_resize_chain_k<1>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    case 2: return launch_resize_chain_k<2>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    case 3: return launch_resize_chain_k<3>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    case 4: return launch_resize_chain_k<4>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -192,6 +192,119 @@ static int resize_plane(kc_plane *src, kc_size size, int filter, kc_plane **out)
     return KC_OK;
 }
 
+// Picks the LDS tile for one resample: the first (widest) tile whose staged source neighbourhood,
+// vertical-pass intermediate and vertical tap table fit in 64 KiB of LDS.
+struct TileChoice {
+    uint32_t tile_w = 0, tile_h = 0, ncp = 0, nrp = 0;
+    bool ok = false;
+};
+
+static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size size)
+{
+    Context &c = ctx();
+    // Wider tiles first: each row of a tile is one contiguous run of 16-byte stores.
+    static const uint32_t tiles[][2] = { { 1024, 16 }, { 512, 16 }, { 256, 64 }, { 256, 32 }, { 256, 16 }, { 128, 16 },
+                                         { 64, 16 },   { 64, 8 },   { 32, 8 },   { 16, 8 },   { 16, 4 } };
+    TileChoice t;
+    for (auto &tl : tiles) {
+        if (c.resize_tile_w > 0 && (tl[0] != (uint32_t)c.resize_tile_w || (c.resize_tile_h > 0 && tl[1] != (uint32_t)c.resize_tile_h)) && tl[0] >= 256) continue;
+        const uint32_t ncp = tile_ncap(th.host, size.width, tl[0]) | 1u;  // odd pitch spreads LDS banks
+        const uint32_t nrp = tile_ncap(tv.host, size.height, tl[1]);
+        if (resize_lds_bytes(tl[1], ncp, nrp, tv.dev.stride) <= 64 * 1024) {
+            t.tile_w = tl[0];
+            t.tile_h = tl[1];
+            t.ncp = ncp;
+            t.nrp = nrp;
+            t.ok = true;
+            break;
+        }
+    }
+    return t;
+}
+
+// Runs the resample src -> dst (both resident).
+static int resize_run(kc_plane *src, kc_plane *dst, int filter)
+{
+    Context &c = ctx();
+    const kc_size size{ dst->w, dst->h };
+    TapsEntry *tv = nullptr, *th = nullptr;
+    KC_TRY(get_taps(src->h, size.height, filter, &tv));
+    KC_TRY(get_taps(src->w, size.width, filter, &th));
+    const uint32_t spitch = (uint32_t)(src->pitch / 4), dpitch = (uint32_t)(dst->pitch / 4);
+    // LDS-tiled single pass when one tile's source neighbourhood + vertical-pass intermediate fit
+    // in 64 KiB of LDS (every up-sample, moderate down-samples); otherwise (very wide windows) two
+    // passes through an HBM intermediate.
+    if (c.resize_mode != 3) {
+        const TileChoice t = choose_tile(*tv, *th, size);
+        if (t.ok) {
+            hipError_t e = launch_resize_lds(src->dptr, spitch, dst->dptr, dpitch, size.width, size.height, tv->dev, th->dev,
+                                             th->host.min_count, t.tile_w, t.tile_h, t.ncp, t.nrp, c.stream);
+            if (e != hipSuccess) return hip_fail(e, "launch_resize_lds");
+            c.launches++;
+            return KC_OK;
+        }
+    }
+    kc_plane *tmp = nullptr;
+    KC_TRY(plane_new_mem(src->w, size.height, &tmp));
+    const uint32_t tpitch = (uint32_t)(tmp->pitch / 4);
+    hipError_t e = launch_resize_vertical(src->dptr, spitch, src->w, tmp->dptr, tpitch, size.height, tv->dev, c.stream);
+    if (e == hipSuccess)
+        e = launch_resize_horizontal(tmp->dptr, tpitch, dst->dptr, dpitch, size.width, size.height, th->dev, c.stream);
+    plane_release(tmp);
+    if (e != hipSuccess) return hip_fail(e, "launch_resize two-pass");
+    c.launches += 2;
+    return KC_OK;
+}
+
+// RESIZE -> MEM through the plain resize kernel.
+int resize_force(kc_plane *p)
+{
+    if (p->kind != kc_plane::RESIZE) return KC_OK;
+    KC_TRY(need_init());
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    kc_plane *dst = nullptr;
+    KC_TRY(plane_new_mem(p->w, p->h, &dst));
+    int s = resize_run(p->rz_src, dst, p->rz_filter);
+    if (s != KC_OK) {
+        plane_release(dst);
+        return s;
+    }
+    p->kind = kc_plane::MEM;
+    p->dptr = dst->dptr;
+    p->pitch = dst->pitch;
+    p->bytes = dst->bytes;
+    p->owned = true;
+    dst->owned = false;
+    dst->dptr = nullptr;
+    plane_release(dst);
+    plane_release(p->rz_src);
+    p->rz_src = nullptr;
+    return KC_OK;
+}
+
+// Fused resample + chain (see kc_runtime.hpp).  Eligible: every channel's resampled operand uses
+// the same tap tables (same source size and filter), at most 4 horizontal taps (held in
+// registers), a {+,-,*} program of at most 16 steps, and an LDS tile exists.
+int chain_resize_launch(const ChainProgram &P, int batch, int mode, kc_plane *const *sampled, bool *launched)
+{
+    Context &c = ctx();
+    *launched = false;
+    if (!c.fusion || c.resize_mode == 3 || mode != 0 || P.n_ops > 16 || P.n_in < 1 || P.n_in > 4) return KC_OK;
+    const kc_plane *s0 = sampled[0];
+    const kc_size size{ s0->w, s0->h };
+    TapsEntry *tv = nullptr, *th = nullptr;
+    KC_TRY(get_taps(s0->rz_src->h, size.height, s0->rz_filter, &tv));
+    KC_TRY(get_taps(s0->rz_src->w, size.width, s0->rz_filter, &th));
+    if (th->host.stride > 4) return KC_OK;
+    const TileChoice t = choose_tile(*tv, *th, size);
+    if (!t.ok) return KC_OK;
+    hipError_t e = launch_resize_chain(P, batch, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, t.nrp,
+                                       c.stream);
+    if (e != hipSuccess) return hip_fail(e, "launch_resize_chain");
+    *launched = true;
+    return KC_OK;
+}
+
 static int resize_plane_uncached(kc_plane *src, kc_size size, int filter, kc_plane **out)
 {
     Context &c = ctx();
@@ -207,58 +320,30 @@ static int resize_plane_uncached(kc_plane *src, kc_size size, int filter, kc_pla
         *out = plane_new_const(size.width, size.height, u);
         return KC_OK;
     }
+    if (filter < KC_FILTER_NEAREST || filter > KC_FILTER_LANCZOS3) {
+        set_error("invalid ResizeFilter");
+        return KC_ERR_INVALID_ARG;
+    }
     KC_TRY(need_init());
     KC_TRY(plane_materialize(src));
-    TapsEntry *tv = nullptr, *th = nullptr;
-    KC_TRY(get_taps(src->h, size.height, filter, &tv));
-    KC_TRY(get_taps(src->w, size.width, filter, &th));
-    kc_plane *dst = nullptr;
-    KC_TRY(plane_new_mem(size.width, size.height, &dst));
-    const uint32_t spitch = (uint32_t)(src->pitch / 4), dpitch = (uint32_t)(dst->pitch / 4);
-
-    // LDS-tiled single pass when one tile's source neighbourhood + vertical-pass intermediate fit
-    // in 64 KiB of LDS (every up-sample, moderate down-samples); otherwise (very wide windows) two
-    // passes through an HBM intermediate.  Bigger tiles first: they amortise the table fetches.
-    static const uint32_t tiles[][2] = { { 1024, 16 }, { 512, 16 }, { 256, 64 }, { 256, 32 }, { 256, 16 }, { 128, 16 },
-                                         { 64, 16 },   { 64, 8 },   { 32, 8 },   { 16, 8 },   { 16, 4 } };
-    bool done = false;
-    if (c.resize_mode != 3) {
-        for (auto &tl : tiles) {
-            if (c.resize_tile_w > 0 && (tl[0] != (uint32_t)c.resize_tile_w || (c.resize_tile_h > 0 && tl[1] != (uint32_t)c.resize_tile_h)) && tl[0] >= 256) continue;
-            const uint32_t ncp = tile_ncap(th->host, size.width, tl[0]) | 1u;  // odd pitch spreads LDS banks
-            const uint32_t nrp = tile_ncap(tv->host, size.height, tl[1]);
-            if (resize_lds_bytes(tl[1], ncp, nrp, tv->dev.stride) <= 64 * 1024) {
-                hipError_t e = launch_resize_lds(src->dptr, spitch, dst->dptr, dpitch, size.width, size.height, tv->dev,
-                                                 th->dev, th->host.min_count, tl[0], tl[1], ncp, nrp, c.stream);
-                if (e != hipSuccess) {
-                    plane_release(dst);
-                    return hip_fail(e, "launch_resize_lds");
-                }
-                c.launches++;
-                done = true;
-                break;
-            }
-        }
-    }
-    if (!done) {
-        kc_plane *tmp = nullptr;
-        int s = plane_new_mem(src->w, size.height, &tmp);
+    // Deferred: a Mix chain that consumes the result resamples inside its own kernel; any other
+    // consumer (or fusion switched off) runs the resize kernel on first use.
+    kc_plane *p = new kc_plane();
+    p->w = size.width;
+    p->h = size.height;
+    p->kind = kc_plane::RESIZE;
+    p->rz_src = src;
+    p->rz_filter = filter;
+    plane_retain(src);
+    *out = p;
+    if (!c.fusion) {
+        int s = resize_force(p);
         if (s != KC_OK) {
-            plane_release(dst);
+            plane_release(p);
+            *out = nullptr;
             return s;
         }
-        const uint32_t tpitch = (uint32_t)(tmp->pitch / 4);
-        hipError_t e = launch_resize_vertical(src->dptr, spitch, src->w, tmp->dptr, tpitch, size.height, tv->dev, c.stream);
-        if (e == hipSuccess)
-            e = launch_resize_horizontal(tmp->dptr, tpitch, dst->dptr, dpitch, size.width, size.height, th->dev, c.stream);
-        plane_release(tmp);
-        if (e != hipSuccess) {
-            plane_release(dst);
-            return hip_fail(e, "launch_resize two-pass");
-        }
-        c.launches += 2;
     }
-    *out = dst;
     return KC_OK;
 }
 

@@ -7,6 +7,8 @@
 
 namespace kc {
 
+static const int KC_RETRY_CHAIN = -1000;  // internal: chain_launch made operands resident, rebuild
+
 static thread_local std::string g_last_error;
 
 Context &ctx()
@@ -142,6 +144,7 @@ void plane_release(kc_plane *p)
     if (!p) return;
     if (p->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         if (p->chain) delete p->chain;
+        if (p->rz_src) plane_release(p->rz_src);
         if (p->owned && p->dptr) pool_free(p->dptr, p->bytes);
         delete p;
     }
@@ -170,28 +173,48 @@ Operand plane_operand(const kc_plane *p)
 
 // ---- building the kernel program for one lazy plane -------------------------------------
 struct BuiltChain {
-    std::vector<const kc_plane *> inputs;  // distinct MEM planes, index = kernel input slot
     ChainProgram prog;
     int mode = 0;  // 0 = {+,-,*}, 1 = + divide, 2 = + pow
+    kc_plane *sampled[KC_CHAIN_MAX_BATCH] = { nullptr, nullptr, nullptr, nullptr };  // RESIZE operand per channel
 };
 
 static int input_index(std::vector<const kc_plane *> &ins, const kc_plane *p)
 {
     for (size_t i = 0; i < ins.size(); ++i)
-        if (ins[i]->dptr == p->dptr && ins[i]->pitch == p->pitch) return (int)i;
+        if (ins[i] == p || (p->kind == kc_plane::MEM && ins[i]->kind == kc_plane::MEM && ins[i]->dptr == p->dptr &&
+                            ins[i]->pitch == p->pitch))
+            return (int)i;
     ins.push_back(p);
     return (int)ins.size() - 1;
 }
 
 // Fills entry `b` of the program from plane `p`'s chain.  When b > 0 the codes / operand
-// pattern must equal entry 0's (returns false otherwise).
+// pattern must equal entry 0's (returns false otherwise).  Resident planes take input slots
+// 0 .. KM-1 in order of appearance; a RESIZE operand (at most one distinct per chain, see
+// chain_prepare) takes slot KM and is recorded in bc.sampled[b].
 static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
 {
     const Chain &ch = *p->chain;
     ChainProgram &P = bc.prog;
     std::vector<const kc_plane *> ins;
-    int start_src = -1;
-    if (ch.start->kind == kc_plane::MEM) start_src = input_index(ins, ch.start);
+    kc_plane *samp = nullptr;
+    // pass 1: slots of the resident planes
+    if (ch.start->kind == kc_plane::MEM) input_index(ins, ch.start);
+    for (auto &st : ch.steps)
+        if (st.operand->kind == kc_plane::MEM) input_index(ins, st.operand);
+    auto slot = [&](kc_plane *q, float *c) -> int {
+        if (q->kind == kc_plane::MEM) return input_index(ins, q);
+        if (q->kind == kc_plane::RESIZE) {
+            samp = q;
+            return -2;
+        }
+        *c = q->cval;
+        return -1;
+    };
+    const int km = (int)ins.size();
+    float c0 = 0.0f;
+    int start_src = slot(ch.start, &c0);
+    if (start_src == -2) start_src = km;
     if (b == 0) {
         std::memset(&P, 0, sizeof(P));
         P.n_ops = (uint32_t)ch.steps.size();
@@ -199,15 +222,12 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
     } else if (P.n_ops != ch.steps.size() || P.start_src != start_src) {
         return false;
     }
-    P.start_c[b] = ch.start->kind == kc_plane::CONST ? ch.start->cval : 0.0f;
+    P.start_c[b] = c0;
     for (size_t i = 0; i < ch.steps.size(); ++i) {
         const ChainStep &st = ch.steps[i];
-        int src = -1;
         float c = 0.0f;
-        if (st.operand->kind == kc_plane::MEM)
-            src = input_index(ins, st.operand);
-        else
-            c = st.operand->cval;
+        int src = slot(st.operand, &c);
+        if (src == -2) src = km;
         uint8_t code = st.code;
         if (code == CH_ADD_R) code = CH_ADD;  // commutative: the same IEEE result
         if (code == CH_MUL_R) code = CH_MUL;
@@ -222,15 +242,45 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
         P.step[b][i].word = word;
         P.step[b][i].c = c;
     }
+    const uint32_t n_in = (uint32_t)km + (samp ? 1u : 0u);
     if (b == 0)
-        P.n_in = (uint32_t)ins.size();
-    else if (P.n_in != ins.size())
+        P.n_in = n_in;
+    else if (P.n_in != n_in || (samp != nullptr) != (bc.sampled[0] != nullptr))
         return false;
-    for (size_t k = 0; k < ins.size(); ++k) {
+    if (samp && b > 0) {
+        const kc_plane *s0 = bc.sampled[0];
+        if (samp->rz_filter != s0->rz_filter || samp->rz_src->w != s0->rz_src->w || samp->rz_src->h != s0->rz_src->h)
+            return false;
+    }
+    bc.sampled[b] = samp;
+    for (int k = 0; k < km; ++k) {
         P.in[b][k] = ins[k]->dptr;
         P.in_pitch[b][k] = (uint32_t)(ins[k]->pitch / 16);
     }
+    if (samp) {
+        P.samp_src[b] = samp->rz_src->dptr;
+        P.samp_pitch[b] = (uint32_t)(samp->rz_src->pitch / 4);
+    }
     return true;
+}
+
+// A chain can carry at most ONE distinct resampled operand into the fused resize+chain kernel;
+// any further RESIZE operands are run through the plain resize kernel first.
+static int chain_prepare(kc_plane *p)
+{
+    Chain &ch = *p->chain;
+    kc_plane *first = nullptr;
+    auto visit = [&](kc_plane *q) -> int {
+        if (q->kind != kc_plane::RESIZE) return KC_OK;
+        if (!first) {
+            first = q;
+            return KC_OK;
+        }
+        return q == first ? KC_OK : resize_force(q);
+    };
+    KC_TRY(visit(ch.start));
+    for (auto &st : ch.steps) KC_TRY(visit(st.operand));
+    return KC_OK;
 }
 
 static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
@@ -250,6 +300,17 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
         P.out[b] = outs[b]->dptr;
         P.out_pitch[b] = (uint32_t)(outs[b]->pitch / 16);
     }
+    bool launched = false;
+    if (bc.sampled[0]) {
+        int s = chain_resize_launch(P, batch, bc.mode, bc.sampled, &launched);
+        if (s != KC_OK || !launched) {
+            for (auto *o : outs) plane_release(o);
+            if (s != KC_OK) return s;
+            // not eligible: run the resamples on their own, the caller rebuilds the program
+            for (int b = 0; b < batch; ++b) KC_TRY(resize_force(bc.sampled[b]));
+            return KC_RETRY_CHAIN;
+        }
+    }
     // Rows can be flattened into one run when every plane is dense (pitch == 16 * row_units).
     bool dense = (size_t)row_units * 16 == outs[0]->pitch;
     for (int b = 0; b < batch && dense; ++b)
@@ -262,10 +323,12 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
         P.rows = p0->h;
         P.row_units = row_units;
     }
-    hipError_t e = launch_chain(P, batch, bc.mode, c.max_blocks, c.chain_unroll, c.stream);
-    if (e != hipSuccess) {
-        for (auto *o : outs) plane_release(o);
-        return hip_fail(e, "launch_chain");
+    if (!launched) {
+        hipError_t e = launch_chain(P, batch, bc.mode, c.max_blocks, c.chain_unroll, c.stream);
+        if (e != hipSuccess) {
+            for (auto *o : outs) plane_release(o);
+            return hip_fail(e, "launch_chain");
+        }
     }
     c.launches++;
     for (int b = 0; b < batch; ++b) {
@@ -291,13 +354,16 @@ int planes_force(kc_plane *const *planes, int n)
     std::vector<kc_plane *> todo;
     for (int i = 0; i < n; ++i) {
         kc_plane *p = planes[i];
-        if (!p || p->kind != kc_plane::LAZY) continue;
+        if (!p) continue;
+        if (p->kind == kc_plane::RESIZE) KC_TRY(resize_force(p));
+        if (p->kind != kc_plane::LAZY) continue;
         bool dup = false;
         for (auto *q : todo) dup |= (q == p);
         if (!dup) todo.push_back(p);
     }
     if (todo.empty()) return KC_OK;  // constants / resident planes: nothing to launch
     KC_TRY(need_init());
+    for (auto *p : todo) KC_TRY(chain_prepare(p));
     size_t i = 0;
     while (i < todo.size()) {
         BuiltChain bc;
@@ -311,7 +377,9 @@ int planes_force(kc_plane *const *planes, int n)
             group[batch++] = todo[j];
             ++j;
         }
-        KC_TRY(chain_launch(bc, group, batch));
+        int s = chain_launch(bc, group, batch);
+        if (s == KC_RETRY_CHAIN) continue;  // resampled operands are resident now: rebuild this group
+        KC_TRY(s);
         i = j;
     }
     return KC_OK;
@@ -323,7 +391,7 @@ int plane_materialize(kc_plane *p)
 {
     KC_TRY(need_init());
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-    if (p->kind == kc_plane::LAZY) return plane_force(p);
+    if (p->kind == kc_plane::LAZY || p->kind == kc_plane::RESIZE) return plane_force(p);
     if (p->kind == kc_plane::CONST) {
         kc_plane *m = nullptr;
         KC_TRY(plane_new_mem(p->w, p->h, &m));
@@ -371,10 +439,11 @@ static uint8_t code_for(int mix, bool acc_is_left)
 static int chain_distinct_inputs(const Chain &ch, const kc_plane *extra)
 {
     std::vector<const kc_plane *> ins;
-    if (ch.start->kind == kc_plane::MEM) input_index(ins, ch.start);
+    auto counts = [](const kc_plane *q) { return q->kind == kc_plane::MEM || q->kind == kc_plane::RESIZE; };
+    if (counts(ch.start)) input_index(ins, ch.start);
     for (auto &s : ch.steps)
-        if (s.operand->kind == kc_plane::MEM) input_index(ins, s.operand);
-    if (extra && extra->kind == kc_plane::MEM) input_index(ins, extra);
+        if (counts(s.operand)) input_index(ins, s.operand);
+    if (extra && counts(extra)) input_index(ins, extra);
     return (int)ins.size();
 }
 

@@ -167,3 +167,60 @@ def test_entry_points_are_thread_safe(kc, orc):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("filt", ["Nearest", "Triangle", "CatmullRom", "Gaussian", "Lanczos3"])
+@pytest.mark.parametrize("small,big", [((16, 12), (128, 96)), ((110, 110), (128, 128)), ((33, 7), (131, 30)),
+                                       ((64, 64), (48, 40)), ((1, 5), (9, 20))])
+def test_resize_fused_into_the_consuming_chain(kc, orc, filt, small, big):
+    """A resized input that only feeds Mix nodes is resampled inside the chain's own kernel
+    (resize_chain_kernel) when its horizontal taps fit in registers; otherwise the plain resize
+    kernel runs first.  Either way: bit-identical to the oracle and to the unfused evaluation."""
+    (sw, sh), (w, h) = small, big
+    a = [splitmix_plane(SEED_A, c, h, w) for c in range(4)]
+    b = [splitmix_plane(SEED_B, c, sh, sw) * np.float32(1.4) - np.float32(0.2) for c in range(4)]
+    if b[0].size >= 8:
+        b[0].reshape(-1)[:4] = [np.nan, np.inf, -0.0, -np.inf]
+
+    def run():
+        tp = kc.TextureProcessor.new()
+        lg = tp.new_live_graph()
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(a)), 0)
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(b)), 1)
+        na = lg.add_node(kc.Node.new(kc.NodeType.Embed(0)))
+        nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(1)))
+        pol = kc.ResizePolicy.SpecificSize(kc.Size(w, h))
+        flt = kc.ResizeFilter.parse(filt)
+        n1 = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)).with_resize_policy(pol).with_resize_filter(flt))
+        n2 = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Multiply)).with_resize_policy(pol).with_resize_filter(flt))
+        n3 = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Subtract)).with_resize_policy(pol).with_resize_filter(flt))
+        lg.connect(na, n1, 0, 0)
+        lg.connect(nb, n1, 0, 1)
+        lg.connect(n1, n2, 0, 0)
+        lg.connect(na, n2, 0, 1)
+        lg.connect(nb, n3, 0, 0)          # the resampled plane on the LEFT this time
+        lg.connect(n2, n3, 0, 1)
+        l0 = kc.stats()["kernel_launches"]
+        planes = lg.await_clean(n3).slot_data(n3, 0).image.planes()
+        return planes, kc.stats()["kernel_launches"] - l0
+
+    fused, launches = run()
+    kc.set_fusion(False)
+    try:
+        unfused, _ = run()
+    finally:
+        kc.set_fusion(True)
+    bu = [orc.resize_plane(p, w, h, filt) for p in b[:3]]
+    want = []
+    for c in range(3):
+        x1 = orc.mix_plane("Add", a[c], bu[c])
+        x2 = orc.mix_plane("Multiply", x1, a[c])
+        want.append(orc.mix_plane("Subtract", bu[c], x2))
+    want.append(np.ones((h, w), np.float32))
+    assert_planes(fused, want, what="fused resize+chain %s" % filt)
+    assert_planes(unfused, want, what="unfused %s" % filt)
+    left, count, _ = orc.resize_taps(sw, w, filt)
+    if int(count.max()) <= 4:
+        assert launches == 1, launches          # resample + 3 Mix nodes x 3 channels: one kernel
+    else:
+        assert launches == 3 + 1, launches      # R, G, B resampled by the plain kernel, then one chain
