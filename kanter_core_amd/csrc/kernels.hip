@@ -576,24 +576,36 @@ __global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P,
     float *outp = P.out[b];
     const uint32_t opitch = P.out_pitch[b] * 4;  // floats
     const bool full = ox + 3 < T.x1;
-    for (uint32_t ty = rg; ty < T.th; ty += row_groups) {
-        const uint32_t oy = T.y0 + ty;
-        f4 in[K][1];
+    // RU tile rows per trip: the chain program is decoded once for RU float4 (its scalar decode is
+    // the expensive part, see chain_run); rows past the tile repeat its last row and are not stored.
+    constexpr int RU = 4;
+    for (uint32_t ty0 = rg; ty0 < T.th; ty0 += RU * row_groups) {
+        f4 in[K][RU];
 #pragma unroll
-        for (int k = 0; k < K - 1; ++k) in[k][0] = inp[k][oy * ipitch[k] + ox / 4];  // whole quad lies inside the pitch
-        float res[4];
-        resize_out_row<1, MAXT>(C, T.tmp + ty * ncp, res);
-        in[K - 1][0] = f4{ res[0], res[1], res[2], res[3] };
-        f4 acc[1];
-        chain_run<K, 1, 0>(P, b, in, acc);
-        float *o = outp + (size_t)oy * opitch + ox;
-        if (full) {
-            *reinterpret_cast<f4 *>(o) = acc[0];
-        } else {
-            const float r4[4] = { acc[0].x, acc[0].y, acc[0].z, acc[0].w };
+        for (int u = 0; u < RU; ++u) {
+            const uint32_t ty = min(ty0 + u * row_groups, T.th - 1);
+            const uint32_t oy = T.y0 + ty;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (ox + e < T.x1) o[e] = r4[e];
+            for (int k = 0; k < K - 1; ++k) in[k][u] = inp[k][oy * ipitch[k] + ox / 4];  // whole quad lies inside the pitch
+            float res[4];
+            resize_out_row<1, MAXT>(C, T.tmp + ty * ncp, res);
+            in[K - 1][u] = f4{ res[0], res[1], res[2], res[3] };
+        }
+        f4 acc[RU];
+        chain_run<K, RU, 0>(P, b, in, acc);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const uint32_t ty = ty0 + u * row_groups;
+            if (ty >= T.th) break;
+            float *o = outp + (size_t)(T.y0 + ty) * opitch + ox;
+            if (full) {
+                *reinterpret_cast<f4 *>(o) = acc[u];
+            } else {
+                const float r4[4] = { acc[u].x, acc[u].y, acc[u].z, acc[u].w };
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ox + e < T.x1) o[e] = r4[e];
+            }
         }
     }
 }

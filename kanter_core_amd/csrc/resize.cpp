@@ -206,8 +206,20 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
     static const uint32_t tiles[][2] = { { 1024, 16 }, { 512, 16 }, { 256, 64 }, { 256, 32 }, { 256, 16 }, { 128, 16 },
                                          { 64, 16 },   { 64, 8 },   { 32, 8 },   { 16, 8 },   { 16, 4 } };
     TileChoice t;
+    if (c.resize_tile_w > 0 && c.resize_tile_h > 0) {  // tuning override (KC_RESIZE_TILE_W / _H)
+        const uint32_t tw = (uint32_t)c.resize_tile_w, tht = (uint32_t)c.resize_tile_h;
+        const uint32_t ncp = tile_ncap(th.host, size.width, tw) | 1u;
+        const uint32_t nrp = tile_ncap(tv.host, size.height, tht);
+        if (tw % 4 == 0 && tw <= 1024 && 256u % (tw / 4) == 0 && resize_lds_bytes(tht, ncp, nrp, tv.dev.stride) <= 64 * 1024) {
+            t.tile_w = tw;
+            t.tile_h = tht;
+            t.ncp = ncp;
+            t.nrp = nrp;
+            t.ok = true;
+            return t;
+        }
+    }
     for (auto &tl : tiles) {
-        if (c.resize_tile_w > 0 && (tl[0] != (uint32_t)c.resize_tile_w || (c.resize_tile_h > 0 && tl[1] != (uint32_t)c.resize_tile_h)) && tl[0] >= 256) continue;
         const uint32_t ncp = tile_ncap(th.host, size.width, tl[0]) | 1u;  // odd pitch spreads LDS banks
         const uint32_t nrp = tile_ncap(tv.host, size.height, tl[1]);
         if (resize_lds_bytes(tl[1], ncp, nrp, tv.dev.stride) <= 64 * 1024) {
