@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the unfused and PCIe-inclusive side measurements")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse the N > 1 control flow on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -80,17 +82,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % max(torch.cuda.device_count(), 1)  # == local_rank on a full node
+    torch.cuda.set_device(device_index)
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     import kanter_core_amd as kc
     from kanter_core_amd import multi_gpu
     from util import SEED_A, SEED_B, splitmix_plane
 
-    kc.init(local_rank)  # raises (no CPU fallback) when the HIP library or the GPU is missing
+    kc.init(device_index)  # raises (no CPU fallback) when the HIP library or the GPU is missing
     # One explicit (non-default) HIP stream shared by torch (events, RCCL ordering) and the library.
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -199,7 +206,7 @@ def main():
             first, last = add_chain(kc, lg, na, nb, sub_nodes)
             branches.append((lg, na, first, last))
         g = branches[0] if branches else None
-        dev = torch.device("cuda", local_rank)
+        dev = torch.device("cuda", device_index)
         import ctypes as C
         from kanter_core_amd import _lib
         L = _lib.load()
@@ -279,7 +286,7 @@ def main():
     wall, dev_s, launches = timed(step, args.steps, args.warmup)
     total_px = node_px
     if world > 1:
-        t = torch.tensor([wall, node_px], device="cuda", dtype=torch.float64)
+        t = torch.tensor([wall, node_px], device=red_dev, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

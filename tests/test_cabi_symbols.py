@@ -54,3 +54,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.lower() or f == "build.py", f
+
+
+def test_rust_binding_source_is_in_sync_with_the_header():
+    """bindings/rust/kanter_core_amd_sys.rs (generated, source only: no Rust toolchain here) declares
+    exactly the header's entry points."""
+    import subprocess
+    import sys
+    rs = os.path.join(ROOT, "bindings", "rust", "kanter_core_amd_sys.rs")
+    before = open(rs).read()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "bindings", "gen_rust.py")], stdout=subprocess.DEVNULL)
+    assert open(rs).read() == before, "re-run bindings/gen_rust.py"
+    declared = sorted(re.findall(r"pub fn (kc_\w+)\(", before))
+    assert declared == declared_symbols()
