@@ -227,6 +227,9 @@ KC_API int kc_node_graph_edges(const kc_node_graph *g, kc_edge *edges, uint32_t 
 KC_API int kc_node_graph_input_slot_id_with_name(const kc_node_graph *g, const char *name, uint32_t *slot_id);  /* :271-276 */
 KC_API int kc_node_graph_output_slot_id_with_name(const kc_node_graph *g, const char *name, uint32_t *slot_id); /* :278-283 */
 KC_API int kc_node_graph_set_mix_type(kc_node_graph *g, uint32_t node_id, int mix_type);               /* :48-63 */
+KC_API int kc_node_graph_set_image_node_path(kc_node_graph *g, uint32_t node_id, const char *path);    /* :65-83 */
+/* Gives an Output node a new (de-collided) name; old_name (may be NULL) receives the previous one. */
+KC_API int kc_node_graph_rename_output_node(kc_node_graph *g, uint32_t node_id, const char *new_name, char *old_name, size_t cap); /* :232-269 */
 
 /* ========================================================================================== *
  * TextureProcessor / LiveGraph -- src/texture_processor.rs:18-115, src/live_graph.rs:63-645.
@@ -248,6 +251,7 @@ KC_API int kc_live_graph_connect(kc_live_graph *lg, uint32_t output_node, uint32
 KC_API int kc_live_graph_remove_edge(kc_live_graph *lg, kc_edge edge);                                  /* :551-566 */
 KC_API int kc_live_graph_disconnect_slot(kc_live_graph *lg, uint32_t node_id, int side, uint32_t slot_id); /* :568-594 */
 KC_API int kc_live_graph_set_mix_type(kc_live_graph *lg, uint32_t node_id, int mix_type);               /* node_mut, :369-374 */
+KC_API int kc_live_graph_rename_output_node(kc_live_graph *lg, uint32_t node_id, const char *new_name, char *old_name, size_t cap); /* :625-627 */
 KC_API int kc_live_graph_set_resize(kc_live_graph *lg, uint32_t node_id, int policy, uint32_t policy_slot, kc_size policy_size, int filter);
 KC_API int kc_live_graph_node_state(const kc_live_graph *lg, uint32_t node_id, int *state);             /* :244-250 */
 KC_API int kc_live_graph_request(kc_live_graph *lg, uint32_t node_id);                                  /* :219-227 */

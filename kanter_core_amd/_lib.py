@@ -100,6 +100,8 @@ SIGNATURES = {
     "kc_node_graph_input_slot_id_with_name": (C.c_int, [c_vp, C.c_char_p, c_u32p]),
     "kc_node_graph_output_slot_id_with_name": (C.c_int, [c_vp, C.c_char_p, c_u32p]),
     "kc_node_graph_set_mix_type": (C.c_int, [c_vp, C.c_uint32, C.c_int]),
+    "kc_node_graph_set_image_node_path": (C.c_int, [c_vp, C.c_uint32, C.c_char_p]),
+    "kc_node_graph_rename_output_node": (C.c_int, [c_vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]),
     "kc_tex_pro_new": (C.c_int, [C.c_uint64, C.POINTER(c_vp)]),
     "kc_tex_pro_free": (C.c_int, [c_vp]),
     "kc_tex_pro_new_live_graph": (C.c_int, [c_vp, C.POINTER(c_vp)]),
@@ -115,6 +117,7 @@ SIGNATURES = {
     "kc_live_graph_remove_edge": (C.c_int, [c_vp, kc_edge]),
     "kc_live_graph_disconnect_slot": (C.c_int, [c_vp, C.c_uint32, C.c_int, C.c_uint32]),
     "kc_live_graph_set_mix_type": (C.c_int, [c_vp, C.c_uint32, C.c_int]),
+    "kc_live_graph_rename_output_node": (C.c_int, [c_vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]),
     "kc_live_graph_set_resize": (C.c_int, [c_vp, C.c_uint32, C.c_int, C.c_uint32, kc_size, C.c_int]),
     "kc_live_graph_node_state": (C.c_int, [c_vp, C.c_uint32, C.POINTER(C.c_int)]),
     "kc_live_graph_request": (C.c_int, [c_vp, C.c_uint32]),

@@ -606,6 +606,15 @@ class NodeGraph:
     def set_mix_type(self, node_id, mix_type):
         _check(_lib.load().kc_node_graph_set_mix_type(self._h, node_id, int(mix_type)))
 
+    def set_image_node_path(self, node_id, path):
+        _check(_lib.load().kc_node_graph_set_image_node_path(self._h, node_id, os.fspath(path).encode()))
+
+    def rename_output_node(self, node_id, new_name):
+        """-> the old name (src/node_graph.rs:232-269)"""
+        buf = C.create_string_buffer(1024)
+        _check(_lib.load().kc_node_graph_rename_output_node(self._h, node_id, new_name.encode(), buf, 1024))
+        return buf.value.decode()
+
 
 # ------------------------------------------------------------------ LiveGraph / TextureProcessor
 class LiveGraph:
@@ -690,6 +699,11 @@ class LiveGraph:
     def set_mix_type(self, node_id, mix_type):
         _check(_lib.load().kc_live_graph_set_mix_type(self._h, node_id, int(mix_type)))
 
+    def rename_output_node(self, node_id, new_name):
+        buf = C.create_string_buffer(1024)
+        _check(_lib.load().kc_live_graph_rename_output_node(self._h, node_id, new_name.encode(), buf, 1024))
+        return buf.value.decode()
+
     def set_resize(self, node_id, policy=None, filt=None):
         policy = policy or ResizePolicy.default()
         filt = ResizeFilter.default() if filt is None else filt
@@ -759,6 +773,20 @@ class LiveGraph:
         _check(_lib.load().kc_live_graph_buffer_rgba(self._h, node_id, slot_id, int(srgb), out.ctypes.data))
         return out
 
+    @staticmethod
+    def try_buffer_rgba(live_graph, node_id, slot_id, srgb=False):
+        """src/live_graph.rs:98-124: the buffer when the node is Clean, else the node is requested and
+        TexProError(InvalidNodeId) is raised -- the caller polls (update() / await_clean() progresses)."""
+        if live_graph.node_state(node_id) == NodeState.Clean:
+            return live_graph.buffer_rgba(node_id, slot_id, srgb)
+        live_graph.request(node_id)
+        raise TexProError(5)
+
+    @staticmethod
+    def try_buffer_srgba(live_graph, node_id, slot_id):
+        """src/live_graph.rs:126-153"""
+        return LiveGraph.try_buffer_rgba(live_graph, node_id, slot_id, srgb=True)
+
     def embed_slot_data_with_id(self, slot_data, embedded_id):
         _check(_lib.load().kc_live_graph_embed_slot_data_with_id(self._h, slot_data.image._h, slot_data.slot_id,
                                                                  int(embedded_id)))
@@ -805,3 +833,13 @@ class TextureProcessor:
     @staticmethod
     def await_slot_data_size(live_graph, node_id, slot_id):
         return live_graph.await_clean(node_id).slot_data_size(node_id, slot_id)
+
+    def processing_node_count(self):
+        """src/texture_processor.rs:107-109: evaluation is synchronous, nothing is ever in flight
+        between calls."""
+        return 0
+
+    def set_max_processing_nodes(self, count):
+        """src/texture_processor.rs:111-114: admission control of the reference's thread-per-node
+        scheduler; kernels are stream-ordered here, so the value is only recorded."""
+        self.max_processing_nodes = int(count)

@@ -62,7 +62,7 @@ int kc_init(int device_ordinal)
     if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
     if (const char *cu = std::getenv("KC_CHAIN_UNROLL")) {
         int v = std::atoi(cu);
-        if (v == 1 || v == 2 || v == 4 || v == 8) c.chain_unroll = v;
+        if (v == 1 || v == 2 || v == 4 || v == 6 || v == 8) c.chain_unroll = v;
     }
     c.inited = true;
     return KC_OK;
@@ -672,6 +672,33 @@ int kc_node_graph_set_mix_type(kc_node_graph *g, uint32_t id, int mix)
     return KC_OK;
 }
 
+static int copy_name(const std::string &s, char *buf, size_t cap)
+{
+    if (buf && cap > 0) {
+        size_t n = std::min(cap - 1, s.size());
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return KC_OK;
+}
+
+int kc_node_graph_set_image_node_path(kc_node_graph *g, uint32_t id, const char *path)
+{
+    KC_ARG(g && path);
+    Node *n = g->g.find(id);
+    if (!n || n->type != KC_NODE_IMAGE) return KC_ERR_INVALID_NODE_ID;
+    n->text = path;
+    return KC_OK;
+}
+
+int kc_node_graph_rename_output_node(kc_node_graph *g, uint32_t id, const char *new_name, char *old_name, size_t cap)
+{
+    KC_ARG(g && new_name);
+    std::string old;
+    KC_TRY(g->g.rename_output_node(id, new_name, &old));
+    return copy_name(old, old_name, cap);
+}
+
 // ---------------------------------------------------------------- TextureProcessor / LiveGraph
 int kc_tex_pro_new(uint64_t memory_threshold, kc_tex_pro **out)
 {
@@ -790,6 +817,15 @@ int kc_live_graph_set_mix_type(kc_live_graph *lg, uint32_t id, int mix)
     if (n->type != KC_NODE_MIX) return KC_ERR_INVALID_NODE_TYPE;
     n->mix_type = mix;
     return KC_OK;
+}
+
+int kc_live_graph_rename_output_node(kc_live_graph *lg, uint32_t id, const char *new_name, char *old_name, size_t cap)
+{
+    LG_LOCK(lg);
+    KC_ARG(new_name);
+    std::string old;
+    KC_TRY(lg->g.rename_output_node(id, new_name, &old));
+    return copy_name(old, old_name, cap);
 }
 
 int kc_live_graph_set_resize(kc_live_graph *lg, uint32_t id, int policy, uint32_t slot, kc_size size, int filter)

@@ -310,6 +310,27 @@ std::vector<uint32_t> NodeGraph::get_parents(uint32_t id) const
     return p;
 }
 
+int NodeGraph::rename_output_node(uint32_t id, const std::string &new_name, std::string *old_name)
+{
+    // :232-269: the node's own name is taken out of the collision list first
+    Node *n = find(id);
+    if (!n) return KC_ERR_INVALID_NODE_ID;
+    if (!n->is_output()) return KC_ERR_INVALID_NODE_TYPE;
+    std::vector<std::string> names;
+    bool skipped = false;
+    for (auto &o : nodes) {
+        if (!o.is_output()) continue;
+        if (!skipped && o.text == n->text) {
+            skipped = true;
+            continue;
+        }
+        names.push_back(o.text);
+    }
+    if (old_name) *old_name = n->text;
+    n->text = avoid_name_collision(names, new_name);
+    return KC_OK;
+}
+
 std::vector<uint32_t> NodeGraph::output_ids() const
 {
     std::vector<uint32_t> out;

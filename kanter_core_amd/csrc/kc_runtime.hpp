@@ -209,6 +209,7 @@ struct NodeGraph {
     std::vector<uint32_t> get_children_recursive(uint32_t id) const;
     std::vector<uint32_t> get_parents(uint32_t id) const;
     std::vector<uint32_t> output_ids() const;
+    int rename_output_node(uint32_t id, const std::string &new_name, std::string *old_name);
     std::vector<Slot> input_slots_of_graph() const;
     std::vector<Slot> output_slots_of_graph() const;
 };

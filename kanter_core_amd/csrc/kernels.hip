@@ -280,6 +280,7 @@ hipError_t launch_chain(const ChainProgram &p, int batch, int mode, int max_bloc
     switch (unroll) {
     case 1: return launch_chain_u<1, 0>(p, batch, total, max_blocks, s);
     case 2: return launch_chain_u<2, 0>(p, batch, total, max_blocks, s);
+    case 6: return launch_chain_u<6, 0>(p, batch, total, max_blocks, s);
     case 8: return launch_chain_u<8, 0>(p, batch, total, max_blocks, s);
     default: return launch_chain_u<4, 0>(p, batch, total, max_blocks, s);
     }

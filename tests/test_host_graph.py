@@ -210,3 +210,34 @@ def test_calculate_size_is_pure_host():
     assert kc.calculate_size(P.SmallestAxes, [(128, 64), (64, 128)]) == (64, 64)
     assert kc.calculate_size(P.SpecificSlot(1), sizes, slot_index=1) == (256, 256)
     assert kc.calculate_size(P.SpecificSlot(1), sizes, slot_index=-1) == (1, 1)
+
+
+def test_rename_output_and_image_path(live_graph):
+    g = NodeGraph.new()
+    a = g.add_node(Node.new(NodeType.OutputGray("out")))
+    b = g.add_node(Node.new(NodeType.OutputRgba("out")))   # becomes out_0
+    img = g.add_node(Node.new(NodeType.Image("a.png")))
+    assert g.rename_output_node(b, "out") == "out_0"        # collides with a -> out_0 again
+    assert g.rename_output_node(a, "albedo") == "out"
+    assert g.rename_output_node(b, "out") == "out_0"        # "out" is free now
+    names = [list(n["node_type"].values())[0] for n in json.loads(g.to_json())["nodes"]]
+    assert names == ["albedo", "out", "a.png"]
+    g.set_image_node_path(img, "b.png")
+    assert json.loads(g.to_json())["nodes"][2]["node_type"] == {"Image": "b.png"}
+    with pytest.raises(TexProError):
+        g.rename_output_node(img, "x")
+    with pytest.raises(TexProError):
+        g.set_image_node_path(a, "x.png")
+    o = live_graph.add_node(Node.new(NodeType.OutputGray("out")))
+    assert live_graph.rename_output_node(o, "height") == "out"
+
+
+def test_try_buffer_rgba_requests_when_not_clean(live_graph):
+    v = live_graph.add_node(Node.new(NodeType.Value(1.0)))
+    out = live_graph.add_node(Node.new(NodeType.OutputGray("out")))
+    live_graph.connect(v, out, 0, 0)
+    with pytest.raises(TexProError) as e:
+        kc.LiveGraph.try_buffer_rgba(live_graph, out, 0)
+    assert e.value.kind == "InvalidNodeId" and live_graph.node_state(out) == NodeState.Requested
+    live_graph.update()
+    assert live_graph.node_state(out) == NodeState.Clean
