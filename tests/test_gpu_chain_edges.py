@@ -224,3 +224,22 @@ def test_resize_fused_into_the_consuming_chain(kc, orc, filt, small, big):
         assert launches == 1, launches          # resample + 3 Mix nodes x 3 channels: one kernel
     else:
         assert launches == 3 + 1, launches      # R, G, B resampled by the plain kernel, then one chain
+
+
+@pytest.mark.parametrize("n_steps,op", [(20, "Add"), (3, "Divide")])
+def test_resize_operand_falls_back_when_the_program_is_not_eligible(kc, orc, n_steps, op):
+    """More than 16 steps, or a divide step, next to a resampled operand: the plain resize kernel
+    runs first, then the ordinary chain kernel.  Same bits."""
+    h, w, sh, sw = 40, 56, 10, 14
+    a = splitmix_plane(SEED_A, 0, h, w) + np.float32(0.5)
+    b = splitmix_plane(SEED_B, 0, sh, sw) * np.float32(0.9) + np.float32(0.05)
+    A, B = gray(kc, a), gray(kc, b)
+    bu = kc.resize_image(B, (w, h))
+    x, want, bo = A, a, orc.resize_plane(b, w, h, "Triangle")
+    l0 = kc.stats()["kernel_launches"]
+    for i in range(n_steps):
+        x = kc.mix_process(x, bu if i % 2 == 0 else A, kc.MixType.parse(op if i % 2 == 0 else "Multiply"))
+        want = orc.mix_plane(op if i % 2 == 0 else "Multiply", want, bo if i % 2 == 0 else a)
+    got = x.planes()
+    assert kc.stats()["kernel_launches"] - l0 == 2
+    assert_planes(got, [want], what="fallback %d %s" % (n_steps, op))
