@@ -355,9 +355,7 @@ int kc_image_materialize(kc_image *img)
 int kc_image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_image **out)
 {
     KC_ARG(out);
-    int s = image_from_u8(host, w, h, channels, out);
-    if (s == KC_OK) KC_HIP(hipStreamSynchronize(ctx().stream));  // host buffer may be reused on return
-    return s;
+    return image_from_u8(host, w, h, channels, out);  // synchronises: host buffer may be reused on return
 }
 
 int kc_image_to_u8(kc_image *img, int srgb, uint8_t *host)

@@ -84,6 +84,8 @@ int image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_
         hipError_t e = hipMemcpyAsync(staging, host, nbytes, hipMemcpyHostToDevice, c.stream);
         if (e == hipSuccess)
             e = launch_from_u8((const uint8_t *)staging, channels, w, h, dp, (uint32_t)(p[0]->pitch / 4), c.stream);
+        // the caller may free `host` as soon as we return (pageable memory can be DMA'd in place)
+        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
         if (e != hipSuccess) s = hip_fail(e, "image_from_u8");
         else c.launches++;
     }
