@@ -88,18 +88,16 @@ hipError_t launch_resize_vertical(const float *src, uint32_t spitch, uint32_t sw
                                   uint32_t dh, TapsDev v, hipStream_t s);
 hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *dst, uint32_t dpitch, uint32_t dw,
                                     uint32_t dh, TapsDev h, hipStream_t s);
-// LDS-tiled single-pass resample.  ncp / nrp = LDS pitch / rows of the staged source tile (>= the
-// widest source window any tile needs, from the host); LDS bytes = resize_lds_bytes(...).
-inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t nrp, uint32_t v_stride)
-{
-    return ((size_t)nrp * ncp + (size_t)tile_h * ncp + 2u * tile_h + (size_t)tile_h * v_stride) * sizeof(float);
-}
+// Tiled single-pass resample.  ncp = LDS pitch in floats of the vertical-pass intermediate: a multiple
+// of 4 that covers the widest 4-aligned source window any tile needs (from the host).  The 32 spare
+// bytes absorb the register-tap form's reads past a short window (discarded, see resize_out_row).
+inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp) { return (size_t)tile_h * ncp * sizeof(float) + 32u; }
 hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
                              uint32_t dh, TapsDev v, TapsDev h, uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h,
-                             uint32_t ncp, uint32_t nrp, hipStream_t s);
+                             uint32_t ncp, hipStream_t s);
 // Fused resample + chain: input slot n_in - 1 of the program is produced by the resampler.
 hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
-                               uint32_t tile_w, uint32_t tile_h, uint32_t ncp, uint32_t nrp, hipStream_t s);
+                               uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);
 hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, float *nx, float *ny,
                                    float *nz, uint32_t opitch, hipStream_t s);
 hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,

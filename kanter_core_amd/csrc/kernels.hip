@@ -376,11 +376,14 @@ hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *ds
     return hipGetLastError();
 }
 
-// Single-pass LDS-tiled form: each workgroup owns a tile_h x tile_w output tile.
-//   stage   the tile's source neighbourhood (nr x nc floats, coalesced rows) and the vertical tap
-//           table of its rows go to LDS once -- the only HBM reads of the resampler;
-//   phase 1 vertical pass LDS -> LDS: the intermediate the two-pass form would write to HBM
-//           (tile_h x nc floats) never leaves the CU;
+// Single-pass tiled form: each workgroup owns a tile_h x tile_w output tile.
+//   phase 1 vertical pass HBM -> LDS: a wave takes one tile row at a time; its lanes own consecutive
+//           4-column groups of the tile's source window and read the source rows of that output
+//           row with 16-byte loads (one contiguous run per row and wave).  Rows shared by
+//           neighbouring output rows are re-read through L1/L2, not HBM.  The row's weights are
+//           fetched with one coalesced load and handed out lane by lane (v_readlane), so the
+//           inner loop is load + multiply + add.  The intermediate the two-pass form would write
+//           to HBM (tile_h x ncp floats) never leaves the CU;
 //   phase 2 horizontal pass out of LDS: every thread owns 4 consecutive output columns for the
 //           whole tile, so its tap windows and (MAXT > 0) its weights sit in registers and the
 //           four results leave as one 16-byte store -- or, in resize_chain_kernel, feed the Mix
@@ -388,7 +391,7 @@ hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *ds
 // Same operands, same order, same roundings as the two-pass form: bit-identical output.
 // Algorithmic bytes per output pixel = 4 * (1 + in_px / out_px).
 struct ResizeTile {
-    uint32_t x0, y0, x1, y1, th, c0, nc;
+    uint32_t x0, y0, x1, y1, th, c0;
     const float *tmp;  // tile_h x ncp vertical-pass intermediate in LDS
 };
 
@@ -414,62 +417,82 @@ static __device__ __forceinline__ void resize_load_cols(ResizeCols<MAXT> &C, con
         if constexpr (MAXT > 0) {
 #pragma unroll
             for (int j = 0; j < MAXT; ++j) {
+                C.wreg[e][j] = C.wh[e][j];  // rows of the table are zero-padded to `stride` entries
                 C.live[e][j] = (uint32_t)j < C.hn[e];
-                C.wreg[e][j] = C.live[e][j] ? C.wh[e][j] : 0.0f;
             }
         }
     }
 }
 
-// Staging + phase 1 for the workgroup's tile; ends with the barrier that publishes `tmp`.
-static __device__ __forceinline__ ResizeTile resize_tile_prologue(float *lds, const float *__restrict__ src,
-                                                                  uint32_t spitch, uint32_t dw, uint32_t dh,
-                                                                  const TapsDev &V, const TapsDev &H, uint32_t tile_w,
-                                                                  uint32_t tile_h, uint32_t ncp, uint32_t nrp)
+static __device__ __forceinline__ float lane_bcast(float v, uint32_t lane_id)  // lane_id uniform
 {
-    float *srcT = lds;                          // nrp x ncp
-    float *tmp = srcT + nrp * ncp;              // tile_h x ncp
-    uint32_t *vl = reinterpret_cast<uint32_t *>(tmp + tile_h * ncp);
-    uint32_t *vn = vl + tile_h;
-    float *vw = reinterpret_cast<float *>(vn + tile_h);  // tile_h x V.stride
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)lane_id));
+}
 
+// Phase 1 for the workgroup's tile; ends with the barrier that publishes `tmp`.
+// `src` rows are 16-byte aligned (plane pitch is a multiple of 16 bytes), so the window starts at
+// c0 = first source column rounded down to a multiple of 4; the last group may run past the
+// source width into the row's pitch padding -- those intermediates are never read by phase 2.
+static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const float *__restrict__ src,
+                                                               uint32_t spitch, uint32_t dw, uint32_t dh,
+                                                               const TapsDev &V, const TapsDev &H, uint32_t tile_w,
+                                                               uint32_t tile_h, uint32_t ncp)
+{
     ResizeTile T;
     T.x0 = blockIdx.x * tile_w;
     T.y0 = blockIdx.y * tile_h;
     T.x1 = min(T.x0 + tile_w, dw);
     T.y1 = min(T.y0 + tile_h, dh);
     T.th = T.y1 - T.y0;
-    T.c0 = H.left[T.x0];
-    T.nc = H.left[T.x1 - 1] + H.count[T.x1 - 1] - T.c0;  // <= ncp (host-checked)
-    T.tmp = tmp;
-    const uint32_t r0 = V.left[T.y0];
-    const uint32_t nr = V.left[T.y1 - 1] + V.count[T.y1 - 1] - r0;  // <= nrp (host-checked)
-    const uint32_t nc = T.nc, th = T.th;
-
-    for (uint32_t i = threadIdx.x; i < th; i += 256u) {
-        vl[i] = V.left[T.y0 + i] - r0;
-        vn[i] = V.count[T.y0 + i];
-    }
-    for (uint32_t i = threadIdx.x; i < th * V.stride; i += 256u) vw[i] = V.w[(size_t)T.y0 * V.stride + i];
-    // i / nc by multiply-high: exact here because i < (nrp + tile_h) * ncp <= 2^14 (64 KiB of LDS)
-    const uint32_t nc_magic = nc > 1 ? 0xFFFFFFFFu / nc + 1u : 0u;
-    auto div_nc = [&](uint32_t i) { return nc > 1 ? __umulhi(i, nc_magic) : i; };
-    for (uint32_t i = threadIdx.x; i < nr * nc; i += 256u) {
-        const uint32_t r = div_nc(i);
-        const uint32_t c = i - r * nc;
-        srcT[r * ncp + c] = src[(size_t)(r0 + r) * spitch + T.c0 + c];
-    }
-    __syncthreads();
-
-    for (uint32_t i = threadIdx.x; i < th * nc; i += 256u) {
-        const uint32_t ty = div_nc(i);
-        const uint32_t cc = i - ty * nc;
-        const uint32_t n = vn[ty];
-        const float *w = vw + ty * V.stride;
-        const float *col = srcT + vl[ty] * ncp + cc;
-        float t = 0.0f;
-        for (uint32_t j = 0; j < n; ++j) t += col[j * ncp] * w[j];
-        tmp[ty * ncp + cc] = t;
+    T.c0 = H.left[T.x0] & ~3u;
+    T.tmp = lds;
+    const uint32_t nq = (H.left[T.x1 - 1] + H.count[T.x1 - 1] - T.c0 + 3u) / 4u;  // <= ncp / 4 (host-checked)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sp4 = spitch / 4u, ncp4 = ncp / 4u;
+    const f4 *src4 = reinterpret_cast<const f4 *>(src + T.c0);
+    f4 *tmp4 = reinterpret_cast<f4 *>(lds);
+    for (uint32_t ty = wave; ty < T.th; ty += 4u) {
+        const uint32_t oy = T.y0 + ty;
+        const uint32_t left = V.left[oy];  // uniform over the wave: scalar loads
+        const uint32_t n = V.count[oy];
+        const float *wp = V.w + (size_t)oy * V.stride;
+        for (uint32_t qb = 0; qb < nq; qb += 64u) {
+            const uint32_t q = min(qb + lane, nq - 1u);  // surplus lanes repeat the last group
+            const f4 *col = src4 + (size_t)left * sp4 + q;
+            f4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (uint32_t jb = 0; jb < n; jb += 64u) {
+                const float wl = jb + lane < n ? wp[jb + lane] : 0.0f;
+                const uint32_t m = min(64u, n - jb);
+                // four source rows in flight per trip; the sum itself stays sequential
+                uint32_t j = 0;
+                for (; j + 4u <= m; j += 4u) {
+                    f4 p[4];
+                    float w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        p[u] = col[(size_t)(jb + j + u) * sp4];
+                        w[u] = lane_bcast(wl, j + u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc.x += p[u].x * w[u];
+                        acc.y += p[u].y * w[u];
+                        acc.z += p[u].z * w[u];
+                        acc.w += p[u].w * w[u];
+                    }
+                }
+                for (; j < m; ++j) {
+                    const f4 p = col[(size_t)(jb + j) * sp4];
+                    const float w = lane_bcast(wl, j);
+                    acc.x += p.x * w;
+                    acc.y += p.y * w;
+                    acc.z += p.z * w;
+                    acc.w += p.w * w;
+                }
+            }
+            if (qb + lane < nq) tmp4[ty * ncp4 + q] = acc;
+        }
     }
     __syncthreads();
     return T;
@@ -511,7 +534,7 @@ template <int MINT, int MAXT>  // horizontal taps: MINT unconditional, up to MAX
 __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict__ src, uint32_t spitch,
                                                          float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
                                                          uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
-                                                         uint32_t tile_h, uint32_t ncp, uint32_t nrp)
+                                                         uint32_t tile_h, uint32_t ncp)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t col_groups = tile_w / 4;         // threads across one tile row
@@ -522,8 +545,8 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict
     const uint32_t ox = x0 + 4 * cg;
     // this thread's 4 output columns (fetched first so the loads overlap the staging)
     ResizeCols<MAXT> C;
-    resize_load_cols<MAXT>(C, H, ox, x1, H.left[x0]);
-    const ResizeTile T = resize_tile_prologue(lds, src, spitch, dw, dh, V, H, tile_w, tile_h, ncp, nrp);
+    resize_load_cols<MAXT>(C, H, ox, x1, H.left[x0] & ~3u);
+    const ResizeTile T = resize_tile_vpass(lds, src, spitch, dw, dh, V, H, tile_w, tile_h, ncp);
     if (ox >= T.x1) return;
     if (ox + 3 < T.x1) {
         // interior columns: one 16-byte store per row
@@ -552,8 +575,7 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict
 // blockIdx.z = channel (each channel resamples its own source plane with the shared tap tables).
 template <int K, int MAXT>
 __global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P, uint32_t dw, uint32_t dh, TapsDev V,
-                                                           TapsDev H, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
-                                                           uint32_t nrp)
+                                                           TapsDev H, uint32_t tile_w, uint32_t tile_h, uint32_t ncp)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t b = blockIdx.z;
@@ -564,8 +586,8 @@ __global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P,
     const uint32_t x0 = blockIdx.x * tile_w, x1 = min(x0 + tile_w, dw);
     const uint32_t ox = x0 + 4 * cg;
     ResizeCols<MAXT> C;
-    resize_load_cols<MAXT>(C, H, ox, x1, H.left[x0]);
-    const ResizeTile T = resize_tile_prologue(lds, P.samp_src[b], P.samp_pitch[b], dw, dh, V, H, tile_w, tile_h, ncp, nrp);
+    resize_load_cols<MAXT>(C, H, ox, x1, H.left[x0] & ~3u);
+    const ResizeTile T = resize_tile_vpass(lds, P.samp_src[b], P.samp_pitch[b], dw, dh, V, H, tile_w, tile_h, ncp);
     if (ox >= T.x1) return;
     const f4 *inp[K > 1 ? K - 1 : 1];
     uint32_t ipitch[K > 1 ? K - 1 : 1];
@@ -614,63 +636,62 @@ __global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P,
 template <int MINT>
 static void launch_resize_lds_t(dim3 grid, size_t lds, hipStream_t s, uint32_t maxt, const float *src, uint32_t spitch,
                                 float *dst, uint32_t dpitch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
-                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp, uint32_t nrp)
+                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp)
 {
 #define KC_RESIZE_LAUNCH(MAXT) \
-    resize_lds_kernel<(MINT <= MAXT ? MINT : MAXT), MAXT><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp)
+    resize_lds_kernel<(MINT <= MAXT ? MINT : MAXT), MAXT><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp)
     if (maxt <= 1) KC_RESIZE_LAUNCH(1);
     else if (maxt == 2) KC_RESIZE_LAUNCH(2);
     else if (maxt == 3) KC_RESIZE_LAUNCH(3);
     else if (maxt == 4) KC_RESIZE_LAUNCH(4);
     else if (maxt <= 6) KC_RESIZE_LAUNCH(6);
     else if (maxt <= 8) KC_RESIZE_LAUNCH(8);
-    else resize_lds_kernel<0, 0><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    else resize_lds_kernel<0, 0><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp);
 #undef KC_RESIZE_LAUNCH
 }
 
 hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
                              uint32_t dh, TapsDev v, TapsDev h, uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h,
-                             uint32_t ncp, uint32_t nrp, hipStream_t s)
+                             uint32_t ncp, hipStream_t s)
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
-    const size_t lds = resize_lds_bytes(tile_h, ncp, nrp, v.stride);
+    const size_t lds = resize_lds_bytes(tile_h, ncp);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h);
     if (h_min_count >= 2)
-        launch_resize_lds_t<2>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+        launch_resize_lds_t<2>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp);
     else
-        launch_resize_lds_t<1>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+        launch_resize_lds_t<1>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp);
     return hipGetLastError();
 }
 
 template <int K>
 static hipError_t launch_resize_chain_k(const ChainProgram &p, dim3 grid, size_t lds, hipStream_t s, uint32_t dw,
-                                        uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
-                                        uint32_t nrp)
+                                        uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp)
 {
     switch (h.stride) {
-    case 1: resize_chain_kernel<K, 1><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp, nrp); break;
-    case 2: resize_chain_kernel<K, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp, nrp); break;
-    case 3: resize_chain_kernel<K, 3><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp, nrp); break;
-    case 4: resize_chain_kernel<K, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp, nrp); break;
+    case 1: resize_chain_kernel<K, 1><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp); break;
+    case 2: resize_chain_kernel<K, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp); break;
+    case 3: resize_chain_kernel<K, 3><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp); break;
+    case 4: resize_chain_kernel<K, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
-                               uint32_t tile_w, uint32_t tile_h, uint32_t ncp, uint32_t nrp, hipStream_t s)
+                               uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s)
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (batch < 1 || batch > KC_CHAIN_MAX_BATCH || p.n_ops < 1 || p.n_ops > KC_CHAIN_MAX_OPS) return hipErrorInvalidValue;
     if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
-    const size_t lds = resize_lds_bytes(tile_h, ncp, nrp, v.stride);
+    const size_t lds = resize_lds_bytes(tile_h, ncp);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h, batch);
     switch (p.n_in) {
-    case 1: return launch_resize_chain_k<1>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
-    case 2: return launch_resize_chain_k<2>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
-    case 3: return launch_resize_chain_k<3>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
-    case 4: return launch_resize_chain_k<4>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp, nrp);
+    case 1: return launch_resize_chain_k<1>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp);
+    case 2: return launch_resize_chain_k<2>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp);
+    case 3: return launch_resize_chain_k<3>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp);
+    case 4: return launch_resize_chain_k<4>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp);
     default: return hipErrorInvalidValue;
     }
 }

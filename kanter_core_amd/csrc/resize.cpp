@@ -113,7 +113,7 @@ static int get_taps(uint32_t in_n, uint32_t out_n, int filter, TapsEntry **out)
     const size_t nl = (size_t)out_n * sizeof(uint32_t);
     const size_t nw = e.host.w.size() * sizeof(float);
     const size_t nl_pad = (nl + 255) / 256 * 256;
-    e.dev_bytes = 2 * nl_pad + (nw + 255) / 256 * 256;
+    e.dev_bytes = 2 * nl_pad + (nw + 32 + 255) / 256 * 256;  // + 32: register-tap loads past the last row
     KC_HIP(hipMalloc(&e.dev_block, e.dev_bytes));
     char *base = (char *)e.dev_block;
     hipError_t err = hipMemcpyAsync(base, e.host.left.data(), nl, hipMemcpyHostToDevice, c.stream);
@@ -133,16 +133,18 @@ static int get_taps(uint32_t in_n, uint32_t out_n, int filter, TapsEntry **out)
     return KC_OK;
 }
 
-// Widest source-column window any tile_w-wide output tile needs.
-static uint32_t tile_ncap(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
+// LDS pitch (floats) for tile_w-wide output tiles: the widest source-column window any tile needs,
+// measured from its first column rounded down to a multiple of 4, in whole 4-column groups.  An odd
+// group count staggers consecutive tile rows over the LDS banks.
+static uint32_t tile_pitch(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
 {
-    uint32_t cap = 1;
+    uint32_t groups = 1;
     for (uint32_t x0 = 0; x0 < out_n; x0 += tile_w) {
         const uint32_t x1 = std::min(out_n, x0 + tile_w);
-        const uint32_t n = h.left[x1 - 1] + h.count[x1 - 1] - h.left[x0];
-        if (n > cap) cap = n;
+        const uint32_t n = (h.left[x1 - 1] + h.count[x1 - 1] - (h.left[x0] & ~3u) + 3u) / 4u;
+        if (n > groups) groups = n;
     }
-    return cap;
+    return 4u * (groups | 1u);
 }
 
 ResizeMemoScope::ResizeMemoScope()
@@ -192,45 +194,39 @@ static int resize_plane(kc_plane *src, kc_size size, int filter, kc_plane **out)
     return KC_OK;
 }
 
-// Picks the LDS tile for one resample: the first (widest) tile whose staged source neighbourhood,
-// vertical-pass intermediate and vertical tap table fit in 64 KiB of LDS.
+// Picks the output tile for one resample: the first candidate whose vertical-pass intermediate
+// (tile_h rows of the tile's source-column window) fits the LDS budget.  Wide tiles make every tile
+// row one long run of 16-byte stores; the budget keeps several workgroups resident per CU.
 struct TileChoice {
-    uint32_t tile_w = 0, tile_h = 0, ncp = 0, nrp = 0;
+    uint32_t tile_w = 0, tile_h = 0, ncp = 0;
     bool ok = false;
 };
 
+static bool tile_fits(const TapsEntry &th, kc_size size, uint32_t tw, uint32_t tht, size_t budget, TileChoice &t)
+{
+    if (tw % 4 != 0 || tw > 1024 || tw == 0 || tht == 0 || 256u % (tw / 4) != 0) return false;
+    const uint32_t ncp = tile_pitch(th.host, size.width, tw);
+    if (resize_lds_bytes(tht, ncp) > budget) return false;
+    t.tile_w = tw;
+    t.tile_h = tht;
+    t.ncp = ncp;
+    t.ok = true;
+    return true;
+}
+
 static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size size)
 {
+    (void)tv;
     Context &c = ctx();
-    // Wider tiles first: each row of a tile is one contiguous run of 16-byte stores.
-    static const uint32_t tiles[][2] = { { 1024, 16 }, { 512, 16 }, { 256, 64 }, { 256, 32 }, { 256, 16 }, { 128, 16 },
-                                         { 64, 16 },   { 64, 8 },   { 32, 8 },   { 16, 8 },   { 16, 4 } };
     TileChoice t;
-    if (c.resize_tile_w > 0 && c.resize_tile_h > 0) {  // tuning override (KC_RESIZE_TILE_W / _H)
-        const uint32_t tw = (uint32_t)c.resize_tile_w, tht = (uint32_t)c.resize_tile_h;
-        const uint32_t ncp = tile_ncap(th.host, size.width, tw) | 1u;
-        const uint32_t nrp = tile_ncap(tv.host, size.height, tht);
-        if (tw % 4 == 0 && tw <= 1024 && 256u % (tw / 4) == 0 && resize_lds_bytes(tht, ncp, nrp, tv.dev.stride) <= 64 * 1024) {
-            t.tile_w = tw;
-            t.tile_h = tht;
-            t.ncp = ncp;
-            t.nrp = nrp;
-            t.ok = true;
-            return t;
-        }
-    }
-    for (auto &tl : tiles) {
-        const uint32_t ncp = tile_ncap(th.host, size.width, tl[0]) | 1u;  // odd pitch spreads LDS banks
-        const uint32_t nrp = tile_ncap(tv.host, size.height, tl[1]);
-        if (resize_lds_bytes(tl[1], ncp, nrp, tv.dev.stride) <= 64 * 1024) {
-            t.tile_w = tl[0];
-            t.tile_h = tl[1];
-            t.ncp = ncp;
-            t.nrp = nrp;
-            t.ok = true;
-            break;
-        }
-    }
+    if (c.resize_tile_w > 0 && c.resize_tile_h > 0 &&  // tuning override (KC_RESIZE_TILE_W / _H)
+        tile_fits(th, size, (uint32_t)c.resize_tile_w, (uint32_t)c.resize_tile_h, 64 * 1024, t))
+        return t;
+    static const uint32_t tiles[][2] = { { 1024, 16 }, { 512, 16 }, { 256, 16 }, { 128, 16 }, { 64, 16 },
+                                         { 64, 8 },    { 32, 8 },   { 16, 8 },   { 16, 4 } };
+    for (size_t budget : { (size_t)20 * 1024, (size_t)64 * 1024 })
+        for (auto &tl : tiles)
+            if (tile_fits(th, size, tl[0], tl[1], budget, t)) return t;
     return t;
 }
 
@@ -250,7 +246,7 @@ static int resize_run(kc_plane *src, kc_plane *dst, int filter)
         const TileChoice t = choose_tile(*tv, *th, size);
         if (t.ok) {
             hipError_t e = launch_resize_lds(src->dptr, spitch, dst->dptr, dpitch, size.width, size.height, tv->dev, th->dev,
-                                             th->host.min_count, t.tile_w, t.tile_h, t.ncp, t.nrp, c.stream);
+                                             th->host.min_count, t.tile_w, t.tile_h, t.ncp, c.stream);
             if (e != hipSuccess) return hip_fail(e, "launch_resize_lds");
             c.launches++;
             return KC_OK;
@@ -310,8 +306,7 @@ int chain_resize_launch(const ChainProgram &P, int batch, int mode, kc_plane *co
     if (th->host.stride > 4) return KC_OK;
     const TileChoice t = choose_tile(*tv, *th, size);
     if (!t.ok) return KC_OK;
-    hipError_t e = launch_resize_chain(P, batch, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, t.nrp,
-                                       c.stream);
+    hipError_t e = launch_resize_chain(P, batch, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, c.stream);
     if (e != hipSuccess) return hip_fail(e, "launch_resize_chain");
     *launched = true;
     return KC_OK;
