@@ -89,9 +89,17 @@ hipError_t launch_resize_vertical(const float *src, uint32_t spitch, uint32_t sw
 hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *dst, uint32_t dpitch, uint32_t dw,
                                     uint32_t dh, TapsDev h, hipStream_t s);
 // Tiled single-pass resample.  ncp = LDS pitch in floats of the vertical-pass intermediate: a multiple
-// of 4 that covers the widest 4-aligned source window any tile needs (from the host).  The 32 spare
-// bytes absorb the register-tap form's reads past a short window (discarded, see resize_out_row).
-inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp) { return (size_t)tile_h * ncp * sizeof(float) + 32u; }
+// of 4 that covers the widest 4-aligned source window any tile needs (from the host).  The 8 spare
+// floats absorb the register-tap form's reads past a short window (discarded, see resize_out_row);
+// the tile rows' vertical tap table follows.
+// Windows of more than KC_RESIZE_REG_TAPS horizontal taps also keep the tile's horizontal tap table there.
+constexpr uint32_t KC_RESIZE_REG_TAPS = 8;
+inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t v_stride, uint32_t tile_w, uint32_t h_stride)
+{
+    size_t n = (size_t)tile_h * ncp + 8u + 2u * tile_h + (size_t)tile_h * v_stride;
+    if (h_stride > KC_RESIZE_REG_TAPS) n += 2u * tile_w + (size_t)tile_w * h_stride;
+    return n * sizeof(float);
+}
 hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
                              uint32_t dh, TapsDev v, TapsDev h, uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h,
                              uint32_t ncp, hipStream_t s);

@@ -385,7 +385,7 @@ hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *ds
 //           inner loop is load + multiply + add.  The intermediate the two-pass form would write
 //           to HBM (tile_h x ncp floats) never leaves the CU;
 //   phase 2 horizontal pass out of LDS: every thread owns 4 consecutive output columns for the
-//           whole tile, so its tap windows and (MAXT > 0) its weights sit in registers and the
+//           whole tile, so its tap windows and weights sit in registers and the
 //           four results leave as one 16-byte store -- or, in resize_chain_kernel, feed the Mix
 //           chain that consumes the resampled plane without ever being written.
 // Same operands, same order, same roundings as the two-pass form: bit-identical output.
@@ -396,12 +396,10 @@ struct ResizeTile {
 };
 
 template <int MAXT>
-struct ResizeCols {  // the 4 output columns a thread owns
-    static constexpr int NT = MAXT > 0 ? MAXT : 1;
-    uint32_t hl[4], hn[4];
-    const float *wh[4];
-    float wreg[4][NT];
-    bool live[4][NT];
+struct ResizeCols {  // the 4 output columns a thread owns: window start (tile-relative), weights, which taps exist
+    uint32_t hl[4];
+    float wreg[4][MAXT];
+    bool live[4][MAXT];
 };
 
 template <int MAXT>
@@ -412,27 +410,25 @@ static __device__ __forceinline__ void resize_load_cols(ResizeCols<MAXT> &C, con
     for (int e = 0; e < 4; ++e) {
         const uint32_t x = min(ox + e, x1 - 1);
         C.hl[e] = H.left[x] - c0;
-        C.hn[e] = H.count[x];
-        C.wh[e] = H.w + (size_t)x * H.stride;
-        if constexpr (MAXT > 0) {
+        const uint32_t hn = H.count[x];
+        const float *wh = H.w + (size_t)x * H.stride;
 #pragma unroll
-            for (int j = 0; j < MAXT; ++j) {
-                C.wreg[e][j] = C.wh[e][j];  // rows of the table are zero-padded to `stride` entries
-                C.live[e][j] = (uint32_t)j < C.hn[e];
-            }
+        for (int j = 0; j < MAXT; ++j) {
+            C.wreg[e][j] = wh[j];  // rows of the table are zero-padded to `stride` entries
+            C.live[e][j] = (uint32_t)j < hn;
         }
     }
-}
-
-static __device__ __forceinline__ float lane_bcast(float v, uint32_t lane_id)  // lane_id uniform
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)lane_id));
 }
 
 // Phase 1 for the workgroup's tile; ends with the barrier that publishes `tmp`.
 // `src` rows are 16-byte aligned (plane pitch is a multiple of 16 bytes), so the window starts at
 // c0 = first source column rounded down to a multiple of 4; the last group may run past the
 // source width into the row's pitch padding -- those intermediates are never read by phase 2.
+// A wave's work items are (tile row, 64-group column block) pairs.  Two items run together and each
+// keeps VU source rows in flight, so a trip is 2 * VU independent 16-byte loads per lane: the
+// tile's latency chain is a handful of round trips, whatever the window size.
+static constexpr int VU = 4;
+
 static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const float *__restrict__ src,
                                                                uint32_t spitch, uint32_t dw, uint32_t dh,
                                                                const TapsDev &V, const TapsDev &H, uint32_t tile_w,
@@ -447,52 +443,83 @@ static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const
     T.c0 = H.left[T.x0] & ~3u;
     T.tmp = lds;
     const uint32_t nq = (H.left[T.x1 - 1] + H.count[T.x1 - 1] - T.c0 + 3u) / 4u;  // <= ncp / 4 (host-checked)
+
+    // the tile rows' vertical taps: one coalesced fetch into LDS
+    uint32_t *vl = reinterpret_cast<uint32_t *>(lds + tile_h * ncp + 8u);
+    uint32_t *vn = vl + tile_h;
+    float *vw = reinterpret_cast<float *>(vn + tile_h);  // tile_h x V.stride
+    for (uint32_t i = threadIdx.x; i < T.th; i += 256u) {
+        vl[i] = V.left[T.y0 + i];
+        vn[i] = V.count[T.y0 + i];
+    }
+    for (uint32_t i = threadIdx.x; i < T.th * V.stride; i += 256u) vw[i] = V.w[(size_t)T.y0 * V.stride + i];
+    __syncthreads();
+
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sp4 = spitch / 4u, ncp4 = ncp / 4u;
     const f4 *src4 = reinterpret_cast<const f4 *>(src + T.c0);
     f4 *tmp4 = reinterpret_cast<f4 *>(lds);
-    for (uint32_t ty = wave; ty < T.th; ty += 4u) {
-        const uint32_t oy = T.y0 + ty;
-        const uint32_t left = V.left[oy];  // uniform over the wave: scalar loads
-        const uint32_t n = V.count[oy];
-        const float *wp = V.w + (size_t)oy * V.stride;
-        for (uint32_t qb = 0; qb < nq; qb += 64u) {
-            const uint32_t q = min(qb + lane, nq - 1u);  // surplus lanes repeat the last group
-            const f4 *col = src4 + (size_t)left * sp4 + q;
-            f4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
-            for (uint32_t jb = 0; jb < n; jb += 64u) {
-                const float wl = jb + lane < n ? wp[jb + lane] : 0.0f;
-                const uint32_t m = min(64u, n - jb);
-                // four source rows in flight per trip; the sum itself stays sequential
-                uint32_t j = 0;
-                for (; j + 4u <= m; j += 4u) {
-                    f4 p[4];
-                    float w[4];
+    const uint32_t nqb = (nq + 63u) / 64u;
+    uint32_t ty = wave, qb = 0;  // next item of this wave: rows wave, wave + 4, ...; column blocks 0 .. nqb-1
+    while (ty < T.th) {
+        uint32_t n[2];
+        const f4 *col[2];
+        const float *w[2];
+        f4 *out[2];
+        bool keep[2];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        p[u] = col[(size_t)(jb + j + u) * sp4];
-                        w[u] = lane_bcast(wl, j + u);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc.x += p[u].x * w[u];
-                        acc.y += p[u].y * w[u];
-                        acc.z += p[u].z * w[u];
-                        acc.w += p[u].w * w[u];
-                    }
-                }
-                for (; j < m; ++j) {
-                    const f4 p = col[(size_t)(jb + j) * sp4];
-                    const float w = lane_bcast(wl, j);
-                    acc.x += p.x * w;
-                    acc.y += p.y * w;
-                    acc.z += p.z * w;
-                    acc.w += p.w * w;
-                }
+        for (int g = 0; g < 2; ++g) {
+            const bool valid = ty < T.th;
+            const uint32_t r = valid ? ty : wave;  // an odd item count pairs the last item with a no-op
+            const uint32_t q = min(qb * 64u + lane, nq - 1u);  // surplus lanes repeat the last group
+            n[g] = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(vn[r]) : 0u;
+            col[g] = src4 + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(vl[r]) * sp4 + q;
+            w[g] = vw + r * V.stride;
+            out[g] = tmp4 + r * ncp4 + q;
+            keep[g] = valid && qb * 64u + lane < nq;
+            if (++qb == nqb) {
+                qb = 0;
+                ty += 4u;
             }
-            if (qb + lane < nq) tmp4[ty * ncp4 + q] = acc;
         }
+        // A lone item uses both load slots for itself: 2 * VU of its taps per trip.
+        const bool lone = n[1] == 0u;
+        const uint32_t nmax = max(n[0], n[1]);
+        const uint32_t second = lone ? VU : 0u;  // tap offset of slot 1
+        const uint32_t n1 = lone ? n[0] : n[1];
+        if (lone) {
+            col[1] = col[0];
+            w[1] = w[0];
+        }
+        f4 acc[2] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } };
+        for (uint32_t j0 = 0; j0 < nmax; j0 += lone ? 2 * VU : VU) {
+            f4 p[2][VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {  // taps past the window re-read its last row and are not summed
+                p[0][u] = col[0][(size_t)min(j0 + u, n[0] - 1u) * sp4];
+                p[1][u] = col[1][(size_t)min(j0 + second + u, max(n1, 1u) - 1u) * sp4];
+            }
+            auto add = [](f4 &a, const f4 &px, float wt) {
+                a.x += px.x * wt;
+                a.y += px.y * wt;
+                a.z += px.z * wt;
+                a.w += px.w * wt;
+            };
+#pragma unroll
+            for (int u = 0; u < VU; ++u)
+                if (j0 + u < n[0]) add(acc[0], p[0][u], w[0][j0 + u]);  // uniform branches
+#pragma unroll
+            for (int u = 0; u < VU; ++u)
+                if (j0 + second + u < n1) {
+                    const float wt = w[1][j0 + second + u];
+                    if (lone) add(acc[0], p[1][u], wt);
+                    else add(acc[1], p[1][u], wt);
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            if (keep[g]) *out[g] = acc[g];
     }
     __syncthreads();
     return T;
@@ -502,7 +529,7 @@ static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const
 template <int MINT, int MAXT>
 static __device__ __forceinline__ void resize_out_row(const ResizeCols<MAXT> &C, const float *row, float (&res)[4])
 {
-    if constexpr (MAXT > 0) {
+    {
         // Taps are contiguous from hl[e]: one base address per output, constant offsets per tap
         // (ds_read2).  A tap past the window reads the next floats of the LDS block -- always
         // inside the allocation (the vertical tap table follows tmp) -- and is discarded below.
@@ -520,17 +547,10 @@ static __device__ __forceinline__ void resize_out_row(const ResizeCols<MAXT> &C,
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) res[e] = clamp01_nan_passthrough(t[e]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = 0.0f;
-            for (uint32_t j = 0; j < C.hn[e]; ++j) t += row[C.hl[e] + j] * C.wh[e][j];
-            res[e] = clamp01_nan_passthrough(t);
-        }
     }
 }
 
-template <int MINT, int MAXT>  // horizontal taps: MINT unconditional, up to MAXT in registers; MAXT = 0: any count
+template <int MINT, int MAXT>  // horizontal taps, all in registers: MINT unconditional, up to MAXT
 __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict__ src, uint32_t spitch,
                                                          float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
                                                          uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
@@ -568,6 +588,49 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict
     }
 }
 
+// Wide horizontal windows (more than 8 taps: down-sampling).  The tile's horizontal tap table is
+// staged in LDS behind the vertical one and every thread produces single outputs, four taps per trip
+// (both operands come from LDS; a tap past the window repeats the last one and adds -0.0).
+__global__ __launch_bounds__(256) void resize_wide_kernel(const float *__restrict__ src, uint32_t spitch,
+                                                          float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
+                                                          uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
+                                                          uint32_t tile_h, uint32_t ncp, uint32_t h_off)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t x0 = blockIdx.x * tile_w, tw = min(x0 + tile_w, dw) - x0;
+    const uint32_t c0 = H.left[x0] & ~3u;
+    uint32_t *hl = reinterpret_cast<uint32_t *>(lds + h_off);
+    uint32_t *hn = hl + tile_w;
+    float *hw = reinterpret_cast<float *>(hn + tile_w);  // tile_w x H.stride
+    for (uint32_t i = threadIdx.x; i < tw; i += 256u) {
+        hl[i] = H.left[x0 + i] - c0;
+        hn[i] = H.count[x0 + i];
+    }
+    for (uint32_t i = threadIdx.x; i < tw * H.stride; i += 256u) hw[i] = H.w[(size_t)x0 * H.stride + i];
+    const ResizeTile T = resize_tile_vpass(lds, src, spitch, dw, dh, V, H, tile_w, tile_h, ncp);  // its barriers publish hl/hn/hw
+    const uint32_t sh = 31u - (uint32_t)__clz((int)tile_w);  // tile_w is a power of two
+    for (uint32_t i = threadIdx.x; i < T.th * tile_w; i += 256u) {
+        const uint32_t ty = i >> sh, x = i & (tile_w - 1u);
+        if (x >= tw) continue;
+        const uint32_t n = hn[x];
+        const float *row = T.tmp + ty * ncp + hl[x];
+        const float *w = hw + x * H.stride;
+        float t = 0.0f;
+        for (uint32_t j0 = 0; j0 < n; j0 += 4u) {
+            float p[4], wt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t jj = min(j0 + u, n - 1u);
+                p[u] = row[jj];
+                wt[u] = w[jj];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t += j0 + u < n ? p[u] * wt[u] : -0.0f;
+        }
+        dst[(size_t)(T.y0 + ty) * dpitch + x0 + x] = clamp01_nan_passthrough(t);
+    }
+}
+
 // Fused resample + Mix chain: phase 2's four results are input slot K-1 of the chain program, the
 // other K-1 inputs are resident planes read with one 16-byte load each, and only the chain's
 // result is stored.  The resampled plane itself never exists in HBM: per output pixel the launch
@@ -585,31 +648,50 @@ __global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P,
     const uint32_t rg = threadIdx.x / col_groups;
     const uint32_t x0 = blockIdx.x * tile_w, x1 = min(x0 + tile_w, dw);
     const uint32_t ox = x0 + 4 * cg;
+    const uint32_t y0 = blockIdx.y * tile_h;
+    const uint32_t th = min(tile_h, dh - y0);
+    constexpr int KM = K > 1 ? K - 1 : 1;
+    const f4 *inp[KM];
+    uint32_t ipitch[KM];
+#pragma unroll
+    for (int k = 0; k < K - 1; ++k) {
+        inp[k] = reinterpret_cast<const f4 *>(P.in[b][k]) + ox / 4;  // the whole quad lies inside the pitch
+        ipitch[k] = P.in_pitch[b][k];
+    }
+    // RU tile rows per trip: the chain program is decoded once for RU float4 (its scalar decode is
+    // the expensive part, see chain_run); rows past the tile repeat its last row and are not stored.
+    // With one resident input, its quads for trip i + 1 are requested before trip i is computed (the
+    // first before the vertical pass): a wave then never waits for loads queued behind its own stores.
+    constexpr int RU = 4;
+    constexpr bool AHEAD = K <= 2;  // 16 more registers per resident input: not worth the occupancy beyond one
+    f4 nxt[KM][RU];
+    auto request = [&](uint32_t ty0) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const uint32_t oy = y0 + min(ty0 + u * row_groups, th - 1);
+#pragma unroll
+            for (int k = 0; k < K - 1; ++k) nxt[k][u] = inp[k][oy * ipitch[k]];
+        }
+    };
+    if (AHEAD && ox < x1) request(rg);
     ResizeCols<MAXT> C;
     resize_load_cols<MAXT>(C, H, ox, x1, H.left[x0] & ~3u);
     const ResizeTile T = resize_tile_vpass(lds, P.samp_src[b], P.samp_pitch[b], dw, dh, V, H, tile_w, tile_h, ncp);
     if (ox >= T.x1) return;
-    const f4 *inp[K > 1 ? K - 1 : 1];
-    uint32_t ipitch[K > 1 ? K - 1 : 1];
-#pragma unroll
-    for (int k = 0; k < K - 1; ++k) {
-        inp[k] = reinterpret_cast<const f4 *>(P.in[b][k]);
-        ipitch[k] = P.in_pitch[b][k];
-    }
     float *outp = P.out[b];
     const uint32_t opitch = P.out_pitch[b] * 4;  // floats
     const bool full = ox + 3 < T.x1;
-    // RU tile rows per trip: the chain program is decoded once for RU float4 (its scalar decode is
-    // the expensive part, see chain_run); rows past the tile repeat its last row and are not stored.
-    constexpr int RU = 4;
     for (uint32_t ty0 = rg; ty0 < T.th; ty0 += RU * row_groups) {
         f4 in[K][RU];
+        if (!AHEAD) request(ty0);
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int k = 0; k < K - 1; ++k) in[k][u] = nxt[k][u];
+        if (AHEAD && ty0 + RU * row_groups < T.th) request(ty0 + RU * row_groups);
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const uint32_t ty = min(ty0 + u * row_groups, T.th - 1);
-            const uint32_t oy = T.y0 + ty;
-#pragma unroll
-            for (int k = 0; k < K - 1; ++k) in[k][u] = inp[k][oy * ipitch[k] + ox / 4];  // whole quad lies inside the pitch
             float res[4];
             resize_out_row<1, MAXT>(C, T.tmp + ty * ncp, res);
             in[K - 1][u] = f4{ res[0], res[1], res[2], res[3] };
@@ -645,8 +727,7 @@ static void launch_resize_lds_t(dim3 grid, size_t lds, hipStream_t s, uint32_t m
     else if (maxt == 3) KC_RESIZE_LAUNCH(3);
     else if (maxt == 4) KC_RESIZE_LAUNCH(4);
     else if (maxt <= 6) KC_RESIZE_LAUNCH(6);
-    else if (maxt <= 8) KC_RESIZE_LAUNCH(8);
-    else resize_lds_kernel<0, 0><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp);
+    else KC_RESIZE_LAUNCH(8);
 #undef KC_RESIZE_LAUNCH
 }
 
@@ -656,9 +737,12 @@ hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
-    const size_t lds = resize_lds_bytes(tile_h, ncp);
+    const size_t lds = resize_lds_bytes(tile_h, ncp, v.stride, tile_w, h.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h);
-    if (h_min_count >= 2)
+    if (h.stride > KC_RESIZE_REG_TAPS)
+        resize_wide_kernel<<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp,
+                                                  (uint32_t)(resize_lds_bytes(tile_h, ncp, v.stride, 0, 0) / sizeof(float)));
+    else if (h_min_count >= 2)
         launch_resize_lds_t<2>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp);
     else
         launch_resize_lds_t<1>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp);
@@ -685,7 +769,7 @@ hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, ui
     if (dw == 0 || dh == 0) return hipSuccess;
     if (batch < 1 || batch > KC_CHAIN_MAX_BATCH || p.n_ops < 1 || p.n_ops > KC_CHAIN_MAX_OPS) return hipErrorInvalidValue;
     if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
-    const size_t lds = resize_lds_bytes(tile_h, ncp);
+    const size_t lds = resize_lds_bytes(tile_h, ncp, v.stride, tile_w, h.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h, batch);
     switch (p.n_in) {
     case 1: return launch_resize_chain_k<1>(p, grid, lds, s, dw, dh, v, h, tile_w, tile_h, ncp);

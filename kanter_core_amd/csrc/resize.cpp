@@ -202,11 +202,11 @@ struct TileChoice {
     bool ok = false;
 };
 
-static bool tile_fits(const TapsEntry &th, kc_size size, uint32_t tw, uint32_t tht, size_t budget, TileChoice &t)
+static bool tile_fits(const TapsEntry &tv, const TapsEntry &th, kc_size size, uint32_t tw, uint32_t tht, size_t budget, TileChoice &t)
 {
     if (tw % 4 != 0 || tw > 1024 || tw == 0 || tht == 0 || 256u % (tw / 4) != 0) return false;
     const uint32_t ncp = tile_pitch(th.host, size.width, tw);
-    if (resize_lds_bytes(tht, ncp) > budget) return false;
+    if (resize_lds_bytes(tht, ncp, tv.dev.stride, tw, th.dev.stride) > budget) return false;
     t.tile_w = tw;
     t.tile_h = tht;
     t.ncp = ncp;
@@ -216,17 +216,17 @@ static bool tile_fits(const TapsEntry &th, kc_size size, uint32_t tw, uint32_t t
 
 static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size size)
 {
-    (void)tv;
     Context &c = ctx();
     TileChoice t;
     if (c.resize_tile_w > 0 && c.resize_tile_h > 0 &&  // tuning override (KC_RESIZE_TILE_W / _H)
-        tile_fits(th, size, (uint32_t)c.resize_tile_w, (uint32_t)c.resize_tile_h, 64 * 1024, t))
+        tile_fits(tv, th, size, (uint32_t)c.resize_tile_w, (uint32_t)c.resize_tile_h, 64 * 1024, t))
         return t;
-    static const uint32_t tiles[][2] = { { 1024, 16 }, { 512, 16 }, { 256, 16 }, { 128, 16 }, { 64, 16 },
-                                         { 64, 8 },    { 32, 8 },   { 16, 8 },   { 16, 4 } };
-    for (size_t budget : { (size_t)20 * 1024, (size_t)64 * 1024 })
+    static const uint32_t tiles[][2] = { { 1024, 16 }, { 1024, 8 }, { 512, 16 }, { 512, 8 }, { 256, 16 }, { 256, 8 },
+                                         { 128, 16 },  { 128, 8 },  { 64, 8 },   { 32, 8 },  { 16, 8 },   { 16, 4 },
+                                         { 8, 4 },     { 4, 4 } };
+    for (size_t budget : { (size_t)40 * 1024, (size_t)64 * 1024 })
         for (auto &tl : tiles)
-            if (tile_fits(th, size, tl[0], tl[1], budget, t)) return t;
+            if (tile_fits(tv, th, size, tl[0], tl[1], budget, t)) return t;
     return t;
 }
 

@@ -59,7 +59,8 @@ def main():
         ("down 4096->3000 tri", 4096, 3000, F.Triangle),
     ]
     tiles = [(1024, 16), (1024, 8), (512, 16), (512, 32), (512, 8), (256, 64), (256, 32), (256, 16), (256, 8), (128, 32),
-             (128, 16), (128, 64), (64, 64), (64, 32), (64, 16), (64, 8), (32, 32), (32, 16), (32, 8), (16, 16), (16, 8), (16, 4)]
+             (128, 16), (128, 64), (64, 64), (64, 32), (64, 16), (64, 8), (32, 32), (32, 16), (32, 8), (16, 16), (16, 8), (16, 4),
+             (64, 4), (32, 4), (128, 4), (128, 8), (8, 4), (8, 8), (256, 4)]
     planes = {}
     for name, s, d, filt in cases:
         if args.cases != "all" and args.cases not in name:
