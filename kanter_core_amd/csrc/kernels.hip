@@ -424,10 +424,65 @@ static __device__ __forceinline__ void resize_load_cols(ResizeCols<MAXT> &C, con
 // `src` rows are 16-byte aligned (plane pitch is a multiple of 16 bytes), so the window starts at
 // c0 = first source column rounded down to a multiple of 4; the last group may run past the
 // source width into the row's pitch padding -- those intermediates are never read by phase 2.
-// A wave's work items are (tile row, 64-group column block) pairs.  Two items run together and each
-// keeps VU source rows in flight, so a trip is 2 * VU independent 16-byte loads per lane: the
-// tile's latency chain is a handful of round trips, whatever the window size.
-static constexpr int VU = 4;
+// Work items are (tile row, 4-column group) pairs dealt out to all 256 lanes; a lane walks its
+// item's window VU source rows at a time (VU independent 16-byte loads in flight), its taps read
+// from the LDS copy of the tile rows' tap table.  Everything is per lane: no scalar-unit work
+// beyond the loop counters (the scalar unit is shared by the CU's four SIMDs).
+// Taps every row of the tile has (j < vmin) are summed unconditionally; the remaining ones are
+// per-lane predicated: a tap past a lane's window repeats its last row and adds -0.0.
+template <int VU>
+static __device__ __forceinline__ void resize_vpass_items(const f4 *__restrict__ src4, uint32_t sp4, f4 *tmp4, uint32_t ncp4,
+                                                          uint32_t th, uint32_t nq, const uint32_t *vl, const uint32_t *vn,
+                                                          const float *vw, uint32_t vstride, uint32_t vmin)
+{
+    auto add = [](f4 &a, const f4 &px, float wt) {
+        a.x += px.x * wt;
+        a.y += px.y * wt;
+        a.z += px.z * wt;
+        a.w += px.w * wt;
+    };
+    const uint32_t items = th * nq;
+    // i / nq by multiply-high: exact here because i < 64 * 256 (tile_h <= 64, 64 KiB of LDS)
+    const uint32_t nq_magic = nq > 1 ? 0xFFFFFFFFu / nq + 1u : 0u;
+    for (uint32_t i = threadIdx.x; i < items; i += 256u) {
+        const uint32_t ty = nq > 1 ? __umulhi(i, nq_magic) : i;
+        const uint32_t q = i - ty * nq;
+        const uint32_t n = vn[ty];
+        const f4 *col = src4 + (size_t)vl[ty] * sp4 + q;
+        const float *w = vw + ty * vstride;
+        f4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+        uint32_t j0 = 0;
+        for (; j0 + VU <= vmin; j0 += VU) {
+            f4 p[VU];
+            float wt[VU];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                p[u] = col[(size_t)(j0 + u) * sp4];
+                wt[u] = w[j0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < VU; ++u) add(acc, p[u], wt[u]);
+        }
+        for (; j0 < vstride; j0 += 4u) {
+            f4 p[4];
+            float wt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                p[u] = col[(size_t)min(j0 + u, n - 1u) * sp4];
+                wt[u] = w[min(j0 + u, vstride - 1u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = j0 + u < n;
+                acc.x += live ? p[u].x * wt[u] : -0.0f;
+                acc.y += live ? p[u].y * wt[u] : -0.0f;
+                acc.z += live ? p[u].z * wt[u] : -0.0f;
+                acc.w += live ? p[u].w * wt[u] : -0.0f;
+            }
+        }
+        tmp4[ty * ncp4 + q] = acc;
+    }
+}
 
 static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const float *__restrict__ src,
                                                                uint32_t spitch, uint32_t dw, uint32_t dh,
@@ -454,73 +509,18 @@ static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const
     }
     for (uint32_t i = threadIdx.x; i < T.th * V.stride; i += 256u) vw[i] = V.w[(size_t)T.y0 * V.stride + i];
     __syncthreads();
+    // fewest taps of any row of this tile (tile_h <= 64: one value per lane, butterfly minimum)
+    uint32_t vmin = (threadIdx.x & 63u) < T.th ? vn[threadIdx.x & 63u] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, off));
+    vmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmin);
 
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t sp4 = spitch / 4u, ncp4 = ncp / 4u;
     const f4 *src4 = reinterpret_cast<const f4 *>(src + T.c0);
     f4 *tmp4 = reinterpret_cast<f4 *>(lds);
-    const uint32_t nqb = (nq + 63u) / 64u;
-    uint32_t ty = wave, qb = 0;  // next item of this wave: rows wave, wave + 4, ...; column blocks 0 .. nqb-1
-    while (ty < T.th) {
-        uint32_t n[2];
-        const f4 *col[2];
-        const float *w[2];
-        f4 *out[2];
-        bool keep[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const bool valid = ty < T.th;
-            const uint32_t r = valid ? ty : wave;  // an odd item count pairs the last item with a no-op
-            const uint32_t q = min(qb * 64u + lane, nq - 1u);  // surplus lanes repeat the last group
-            n[g] = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(vn[r]) : 0u;
-            col[g] = src4 + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(vl[r]) * sp4 + q;
-            w[g] = vw + r * V.stride;
-            out[g] = tmp4 + r * ncp4 + q;
-            keep[g] = valid && qb * 64u + lane < nq;
-            if (++qb == nqb) {
-                qb = 0;
-                ty += 4u;
-            }
-        }
-        // A lone item uses both load slots for itself: 2 * VU of its taps per trip.
-        const bool lone = n[1] == 0u;
-        const uint32_t nmax = max(n[0], n[1]);
-        const uint32_t second = lone ? VU : 0u;  // tap offset of slot 1
-        const uint32_t n1 = lone ? n[0] : n[1];
-        if (lone) {
-            col[1] = col[0];
-            w[1] = w[0];
-        }
-        f4 acc[2] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } };
-        for (uint32_t j0 = 0; j0 < nmax; j0 += lone ? 2 * VU : VU) {
-            f4 p[2][VU];
-#pragma unroll
-            for (int u = 0; u < VU; ++u) {  // taps past the window re-read its last row and are not summed
-                p[0][u] = col[0][(size_t)min(j0 + u, n[0] - 1u) * sp4];
-                p[1][u] = col[1][(size_t)min(j0 + second + u, max(n1, 1u) - 1u) * sp4];
-            }
-            auto add = [](f4 &a, const f4 &px, float wt) {
-                a.x += px.x * wt;
-                a.y += px.y * wt;
-                a.z += px.z * wt;
-                a.w += px.w * wt;
-            };
-#pragma unroll
-            for (int u = 0; u < VU; ++u)
-                if (j0 + u < n[0]) add(acc[0], p[0][u], w[0][j0 + u]);  // uniform branches
-#pragma unroll
-            for (int u = 0; u < VU; ++u)
-                if (j0 + second + u < n1) {
-                    const float wt = w[1][j0 + second + u];
-                    if (lone) add(acc[0], p[1][u], wt);
-                    else add(acc[1], p[1][u], wt);
-                }
-        }
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-            if (keep[g]) *out[g] = acc[g];
-    }
+    if (V.stride <= 4u)
+        resize_vpass_items<4>(src4, spitch / 4u, tmp4, ncp / 4u, T.th, nq, vl, vn, vw, V.stride, vmin);
+    else
+        resize_vpass_items<8>(src4, spitch / 4u, tmp4, ncp / 4u, T.th, nq, vl, vn, vw, V.stride, vmin);
     __syncthreads();
     return T;
 }
@@ -736,7 +736,7 @@ hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint
                              uint32_t ncp, hipStream_t s)
 {
     if (dw == 0 || dh == 0) return hipSuccess;
-    if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
+    if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0 || tile_h > 64) return hipErrorInvalidValue;
     const size_t lds = resize_lds_bytes(tile_h, ncp, v.stride, tile_w, h.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h);
     if (h.stride > KC_RESIZE_REG_TAPS)
@@ -768,7 +768,7 @@ hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, ui
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (batch < 1 || batch > KC_CHAIN_MAX_BATCH || p.n_ops < 1 || p.n_ops > KC_CHAIN_MAX_OPS) return hipErrorInvalidValue;
-    if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0) return hipErrorInvalidValue;
+    if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0 || tile_h > 64) return hipErrorInvalidValue;
     const size_t lds = resize_lds_bytes(tile_h, ncp, v.stride, tile_w, h.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h, batch);
     switch (p.n_in) {

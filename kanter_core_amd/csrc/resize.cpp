@@ -133,10 +133,9 @@ static int get_taps(uint32_t in_n, uint32_t out_n, int filter, TapsEntry **out)
     return KC_OK;
 }
 
-// LDS pitch (floats) for tile_w-wide output tiles: the widest source-column window any tile needs,
-// measured from its first column rounded down to a multiple of 4, in whole 4-column groups.  An odd
-// group count staggers consecutive tile rows over the LDS banks.
-static uint32_t tile_pitch(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
+// The widest source-column window any tile_w-wide output tile needs, measured from its first column
+// rounded down to a multiple of 4, in whole 4-column groups.
+static uint32_t tile_groups(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
 {
     uint32_t groups = 1;
     for (uint32_t x0 = 0; x0 < out_n; x0 += tile_w) {
@@ -144,8 +143,11 @@ static uint32_t tile_pitch(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
         const uint32_t n = (h.left[x1 - 1] + h.count[x1 - 1] - (h.left[x0] & ~3u) + 3u) / 4u;
         if (n > groups) groups = n;
     }
-    return 4u * (groups | 1u);
+    return groups;
 }
+
+// LDS pitch in floats for such tiles; an odd group count staggers consecutive tile rows over the banks.
+static uint32_t tile_pitch(const TapsHost &h, uint32_t out_n, uint32_t tile_w) { return 4u * (tile_groups(h, out_n, tile_w) | 1u); }
 
 ResizeMemoScope::ResizeMemoScope()
 {
@@ -204,7 +206,7 @@ struct TileChoice {
 
 static bool tile_fits(const TapsEntry &tv, const TapsEntry &th, kc_size size, uint32_t tw, uint32_t tht, size_t budget, TileChoice &t)
 {
-    if (tw % 4 != 0 || tw > 1024 || tw == 0 || tht == 0 || 256u % (tw / 4) != 0) return false;
+    if (tw % 4 != 0 || tw > 1024 || tw == 0 || tht == 0 || tht > 64 || 256u % (tw / 4) != 0) return false;
     const uint32_t ncp = tile_pitch(th.host, size.width, tw);
     if (resize_lds_bytes(tht, ncp, tv.dev.stride, tw, th.dev.stride) > budget) return false;
     t.tile_w = tw;
@@ -221,9 +223,15 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
     if (c.resize_tile_w > 0 && c.resize_tile_h > 0 &&  // tuning override (KC_RESIZE_TILE_W / _H)
         tile_fits(tv, th, size, (uint32_t)c.resize_tile_w, (uint32_t)c.resize_tile_h, 64 * 1024, t))
         return t;
+    // Wide horizontal windows (down-sampling): the vertical pass re-reads window rows per output row,
+    // so small tiles -- many workgroups, short dependent chains -- win (profiles/resize_tile_sweep.py).
+    static const uint32_t wide[][2] = { { 32, 4 }, { 16, 4 }, { 8, 4 }, { 4, 4 } };
     static const uint32_t tiles[][2] = { { 1024, 16 }, { 1024, 8 }, { 512, 16 }, { 512, 8 }, { 256, 16 }, { 256, 8 },
                                          { 128, 16 },  { 128, 8 },  { 64, 8 },   { 32, 8 },  { 16, 8 },   { 16, 4 },
                                          { 8, 4 },     { 4, 4 } };
+    if (th.dev.stride > KC_RESIZE_REG_TAPS)
+        for (auto &tl : wide)
+            if (tile_fits(tv, th, size, tl[0], tl[1], 64 * 1024, t)) return t;
     for (size_t budget : { (size_t)40 * 1024, (size_t)64 * 1024 })
         for (auto &tl : tiles)
             if (tile_fits(tv, th, size, tl[0], tl[1], budget, t)) return t;
@@ -239,9 +247,8 @@ static int resize_run(kc_plane *src, kc_plane *dst, int filter)
     KC_TRY(get_taps(src->h, size.height, filter, &tv));
     KC_TRY(get_taps(src->w, size.width, filter, &th));
     const uint32_t spitch = (uint32_t)(src->pitch / 4), dpitch = (uint32_t)(dst->pitch / 4);
-    // LDS-tiled single pass when one tile's source neighbourhood + vertical-pass intermediate fit
-    // in 64 KiB of LDS (every up-sample, moderate down-samples); otherwise (very wide windows) two
-    // passes through an HBM intermediate.
+    // Tiled single pass when a tile's vertical-pass intermediate and tap tables fit in LDS; very wide
+    // windows fall back to two passes through an HBM intermediate (KC_RESIZE_MODE=3 forces them).
     if (c.resize_mode != 3) {
         const TileChoice t = choose_tile(*tv, *th, size);
         if (t.ok) {

@@ -1,11 +1,12 @@
 #!/bin/bash
-# SQ-side PMC counters (issue / wait / LDS) for one bench workload: profiles/run_pmc_sq.sh <tag> <bench args...>
+# SQ-side PMC counters (issue / wait / LDS): profiles/run_pmc_sq.sh <tag> <bench args...>
+#   or, for another script: SCRIPT=profiles/resize_one.py profiles/run_pmc_sq.sh <tag> <script args...>
 set -u
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $*"
+if [ -n "${SCRIPT:-}" ]; then ARGS="$GRAFT_REPO_ROOT/$SCRIPT $*"; else ARGS="$GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $*"; fi
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))

@@ -137,11 +137,61 @@ def test_resize_bit_exact(kc, orc, filt, src, dst):
     assert bit_equal(got, want), "%s %s->%s max ulp %s" % (filt, src, dst, max_ulp(got, want))
 
 
+# Several tiles in both directions, widths that are not multiples of 4, every kernel form:
+# register taps (<= 8 per output), LDS tap table (wide windows), up in one axis and down in the other.
+@pytest.mark.parametrize("filt,src,dst", [
+    ("Triangle", (130, 50), (2050, 90)),      # two 1024-wide tiles, partial last quad
+    ("Lanczos3", (130, 50), (1031, 41)),      # 8 register taps
+    ("Triangle", (1030, 70), (515, 35)),      # down 2x: 5 register taps
+    ("CatmullRom", (1030, 70), (515, 35)),    # down 2x: 9 taps -> LDS tap table
+    ("Triangle", (520, 133), (65, 17)),       # down 8x, three column tiles of the wide kernel
+    ("Lanczos3", (333, 520), (41, 65)),       # down ~8x, 49 taps per axis
+    ("Gaussian", (64, 512), (512, 64)),       # up horizontally, down vertically
+    ("Triangle", (512, 64), (64, 512)),       # down horizontally, up vertically
+    ("Nearest", (1000, 9), (37, 1)),
+    ("Triangle", (4096, 3), (3000, 2)),
+])
+def test_resize_bit_exact_many_tiles(kc, orc, filt, src, dst):
+    (sw, sh), (dw, dh) = src, dst
+    p = splitmix_plane(SEED_B, 2, sh, sw) * np.float32(1.5) - np.float32(0.25)
+    p.reshape(-1)[5:9] = [np.nan, np.inf, -np.inf, -0.0]
+    p[-1, -1] = np.inf  # last source column / row: read by the final, partial 4-column group
+    got = kc.resize_image(kc.SlotImage.from_planes([p]), (dw, dh), kc.ResizeFilter.parse(filt)).planes()[0]
+    want = orc.resize_plane(p, dw, dh, filt)
+    assert bit_equal(got, want), "%s %s->%s max ulp %s" % (filt, src, dst, max_ulp(got, want))
+
+
 def test_resize_two_pass_fallback_matches(kc, orc):
-    # a down-sampling window too wide for a 64 KiB LDS tile (needs > 4096 source columns per tile)
+    # a down-sampling window too wide for the smallest LDS tile (about 4096 source columns per output)
     p = splitmix_plane(SEED_B, 1, 8, 8192)
+    l0 = kc.stats()["kernel_launches"]
     got = kc.resize_image(kc.SlotImage.from_planes([p]), (12, 5), kc.ResizeFilter.Lanczos3).planes()[0]
+    assert kc.stats()["kernel_launches"] - l0 == 2, "expected the vertical + horizontal kernels"
     assert bit_equal(got, orc.resize_plane(p, 12, 5, "Lanczos3"))
+
+
+def test_resize_source_in_wrapped_memory_with_tight_pitch(kc, orc):
+    """16-byte loads may touch the pitch padding of a row, never the next allocation: a caller-owned
+    source whose pitch is exactly 16 * ceil(w / 4) bytes, last row at the end of its buffer."""
+    import ctypes as C
+    import torch
+    from kanter_core_amd import _lib
+    L = _lib.load()
+    h, w = 19, 10
+    pitch_f = 12
+    t = torch.full((h, pitch_f), float("nan"), device="cuda")
+    p = splitmix_plane(SEED_A, 3, h, w)
+    t[:, :w] = torch.from_numpy(p).cuda()
+    torch.cuda.synchronize()
+    plane, img = C.c_void_p(), C.c_void_p()
+    assert L.kc_plane_wrap(t.data_ptr(), w, h, pitch_f * 4, C.byref(plane)) == 0
+    L.kc_image_gray(plane, C.byref(img))
+    src = kc.SlotImage(img.value)
+    for dst, filt in (((37, 40), "Triangle"), ((5, 4), "Lanczos3"), ((10, 38), "CatmullRom")):
+        got = kc.resize_image(src, dst, kc.ResizeFilter.parse(filt)).planes()[0]
+        assert bit_equal(got, orc.resize_plane(p, dst[0], dst[1], filt)), (dst, filt)
+    L.kc_plane_release(plane)
+    assert L.kc_plane_wrap(t.data_ptr(), w, h, 40, C.byref(plane)) != 0  # pitch not a multiple of 16 bytes
 
 
 def test_resize_1x1_value_broadcast_is_clamped_constant(kc, orc):
