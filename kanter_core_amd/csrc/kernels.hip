@@ -797,21 +797,84 @@ static __device__ __forceinline__ void vnorm3(float x, float y, float z, float &
 // of the nine IEEE divisions per pixel; this kernel is bound by divide / sqrt issue, not by HBM.
 static __device__ __forceinline__ float zero_over(float n) { return n != n ? n : 0.0f; }
 
+// Several IEEE divisions by one denominator.  This is the compiler's own correctly rounded f32
+// division (v_div_scale / v_rcp / Newton steps / v_div_fmas / v_div_fixup) with the steps that depend
+// only on the denominator done once -- valid where v_div_scale would not rescale and v_div_fixup
+// would not intervene: b normal with a normal reciprocal, a == 0 or |a| >= 2^-103, a / b normal and
+// exponent(a) - exponent(b) < 96.  h2n_px establishes those bounds before taking this path.
+struct SharedDenominator {
+    float nb, r;  // -b, reciprocal after one Newton step
+};
+
+static __device__ __forceinline__ SharedDenominator shared_denominator(float b)
+{
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r0, 1.0f);
+    return { -b, __builtin_fmaf(e, r0, r0) };
+}
+
+template <bool MAY_BE_ZERO = true>
+static __device__ __forceinline__ float divide_by(const SharedDenominator &d, float a)
+{
+    const float m = a * d.r;
+    const float f2 = __builtin_fmaf(d.nb, m, a);
+    const float f3 = __builtin_fmaf(f2, d.r, m);
+    const float f4 = __builtin_fmaf(d.nb, f3, a);
+    const float q = __builtin_fmaf(f4, d.r, f3);
+    // b > 0: the quotient has a's sign; for a == -0 the steps above give +0, so put the sign back
+    return MAY_BE_ZERO ? __builtin_copysignf(q, a) : q;
+}
+
+// sqrt for normal x without the compiler's denormal scaling and +-1 ulp fix-up: the rsq / Newton /
+// residual sequence LLVM itself uses when denormals are flushed.  Correctly rounded on [2^-96, 2^100)
+// (every value checked against sqrtf: profiles/exact_math_check.hip).
+static __device__ __forceinline__ float sqrt_normal(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y;
+    const float h0 = y * 0.5f;
+    const float e = __builtin_fmaf(-h0, s0, 0.5f);
+    const float h = __builtin_fmaf(h0, e, h0);
+    const float s = __builtin_fmaf(s0, e, s0);
+    const float d = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(d, h, s);
+}
+
 static __device__ __forceinline__ void h2n_px(float px, float up, float left, float pdx, float pdy, float &r, float &g,
                                               float &b)
 {
     // tangent = (pdx, 0, px - left) / |.|, bitangent = (0, pdy, up - px) / |.|;
     // |v| = sqrt((x*x + y*y) + z*z) and x*x + 0*0 == x*x exactly
     const float tz0 = px - left, bz0 = up - px;
-    const float n1 = sqrtf(pdx * pdx + tz0 * tz0);
-    const float n2 = sqrtf(pdy * pdy + bz0 * bz0);
-    const float tx = pdx / n1, ty = zero_over(n1), tz = tz0 / n1;
-    const float bx = zero_over(n2), by = pdy / n2, bz = bz0 / n2;
-    const float cx = ty * bz - tz * by;
-    const float cy = tz * bx - tx * bz;
-    const float cz = tx * by - ty * bx;
+    const float q1 = pdx * pdx + tz0 * tz0, q2 = pdy * pdy + bz0 * bz0;
+    // Height steps that are 0 or within [2^-40, 2^7] (and 2^-16 <= pdx, pdy <= 1: sizes are at most
+    // 65535) keep every operation below inside the bounds of sqrt_normal / SharedDenominator:
+    // q1, q2 in [2^-32, 2^15], n1, n2 in [2^-16, 2^7.5], tangent parts in {0} u [2^-47.5, 1], cross
+    // products in {0} u [2^-71, 1], cz >= 2^-47, so |cross|^2 in [2^-94, 3].
+    const float atz = fabsf(tz0), abz = fabsf(bz0);
+    const bool tame = (tz0 == 0.0f || (atz >= 0x1p-40f && atz <= 0x1p7f)) && (bz0 == 0.0f || (abz >= 0x1p-40f && abz <= 0x1p7f));
     float nx, ny, nz;
-    vnorm3(cx, cy, cz, nx, ny, nz);
+    if (tame) {
+        const SharedDenominator d1 = shared_denominator(sqrt_normal(q1)), d2 = shared_denominator(sqrt_normal(q2));
+        const float tx = divide_by<false>(d1, pdx), tz = divide_by(d1, tz0);
+        const float by = divide_by<false>(d2, pdy), bz = divide_by(d2, bz0);
+        const float ty = 0.0f, bx = 0.0f;  // 0 / n
+        const float cx = ty * bz - tz * by;
+        const float cy = tz * bx - tx * bz;
+        const float cz = tx * by - ty * bx;
+        const SharedDenominator d3 = shared_denominator(sqrt_normal((cx * cx + cy * cy) + cz * cz));
+        nx = divide_by(d3, cx);
+        ny = divide_by(d3, cy);
+        nz = divide_by<false>(d3, cz);  // cz = tx * by > 0
+    } else {
+        const float n1 = sqrtf(q1), n2 = sqrtf(q2);
+        const float tx = pdx / n1, ty = zero_over(n1), tz = tz0 / n1;
+        const float bx = zero_over(n2), by = pdy / n2, bz = bz0 / n2;
+        const float cx = ty * bz - tz * by;
+        const float cy = tz * bx - tx * bz;
+        const float cz = tx * by - ty * bx;
+        vnorm3(cx, cy, cz, nx, ny, nz);
+    }
     r = nx * 0.5f + 0.5f;
     g = ny * 0.5f + 0.5f;
     b = nz * 0.5f + 0.5f;

@@ -214,6 +214,23 @@ def test_height_to_normal(kc, orc, shape):
     assert kc.height_to_normal_process(kc.SlotImage.from_value((2, 2), 0.0, True)) is None
 
 
+def test_height_to_normal_across_magnitudes(kc, orc):
+    """Height steps from 2^-60 to 2^30, flat runs, and random mantissas: both the shared-denominator
+    division path (steps of 0 or 2^-40 .. 2^7) and the general one, pixel by pixel against the oracle."""
+    rng = np.random.default_rng(7)
+    h, w = 384, 512
+    step = np.ldexp(rng.random((h, w)) + 0.5, rng.integers(-60, 31, (h, w))).astype(np.float32)
+    step *= rng.choice(np.array([-1.0, 0.0, 1.0], np.float32), (h, w), p=[0.4, 0.2, 0.4])
+    p = np.cumsum(step, axis=1, dtype=np.float32)
+    p[:64] = np.ldexp(rng.random((64, w)), rng.integers(-45, -35, (64, w))).astype(np.float32)  # around the 2^-40 bound
+    p[64:128] = np.ldexp(rng.random((64, w)), rng.integers(4, 11, (64, w))).astype(np.float32)  # around the 2^7 bound
+    p[128:160] = 0.25  # flat: every step is +0
+    p[160, :8] = [np.nan, np.inf, -np.inf, -0.0, 0.0, 1e-45, -1e-45, 3e38]
+    got = kc.height_to_normal_process(kc.SlotImage.from_planes([p]))
+    nx, ny, nz = orc.height_to_normal(p)
+    assert_planes(got.planes(), [nx, ny, nz, np.ones_like(p)], ulp=0, what="h2n magnitudes")
+
+
 @pytest.mark.parametrize("srgb", [False, True])
 @pytest.mark.parametrize("shape", [(32, 32), (7, 13)])
 def test_to_u8(kc, orc, shape, srgb):
