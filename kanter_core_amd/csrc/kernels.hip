@@ -13,11 +13,20 @@ namespace kc {
 
 static __device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
 
-// f32::powf (src/node/mix.rs:189): evaluated in f64 and rounded once, so the result is the
-// correctly rounded f32 power (<= 1 ulp from any libm powf) and every IEEE special case
-// (pow(x, 0) = 1, pow(1, NaN) = 1, negative base with non-integer exponent = NaN ...) follows
-// the f64 routine's identical rules.
-static __device__ __noinline__ float kc_powf(float a, float b) { return (float)pow((double)a, (double)b); }
+// f32::powf (src/node/mix.rs:189), evaluated in f64 and rounded to f32 once.
+// Positive finite base, finite exponent (every pixel of ordinary image data): 2^(b * log2 a) -- the f64
+// log2 / exp2 carry a relative error near 2^-50, |b * log2 a| < 2^11 where the result is finite, so
+// the value rounded to f32 is within 2^-40 relative of exact: the correctly rounded power except
+// when the exact one lies that close to a rounding boundary (then the neighbour; <= 1 ulp either way).
+// Everything else (zero, negative, infinite or NaN base, infinite or NaN exponent) takes the f64 pow
+// routine, whose special-case rules are powf's: pow(x, 0) = 1, pow(1, NaN) = 1, negative base with a
+// non-integer exponent = NaN, signed zeros and infinities by the exponent's parity ...
+static __device__ __noinline__ float kc_powf(float a, float b)
+{
+    if (a > 0.0f && a < __builtin_inff() && __builtin_fabsf(b) < __builtin_inff())
+        return (float)exp2((double)b * log2((double)a));
+    return (float)pow((double)a, (double)b);
+}
 
 template <int CODE>
 static __device__ __forceinline__ float apply1(float acc, float x)
