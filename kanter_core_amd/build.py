@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libkanter_core_amd.so")
 SOURCES = ["kernels.hip", "runtime.cpp", "ops.cpp", "resize.cpp", "graph.cpp", "json.cpp", "png.cpp", "c_api.cpp"]
-HEADERS = ["kc_internal.hpp", "kc_runtime.hpp", os.path.join("..", "..", "include", "kanter_core_amd.h")]
+HEADERS = ["kc_internal.hpp", "kc_runtime.hpp", os.path.join("..", "..", "include", "kanter_core_amd.h"), "pow_positive.inc"]
 
 # -ffp-contract=off and IEEE divide/sqrt are parity requirements (the reference's Rust loops never
 # fuse a*b+c and divide exactly); see INTEGRATION.md.

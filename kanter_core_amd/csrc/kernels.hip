@@ -13,19 +13,21 @@ namespace kc {
 
 static __device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
 
-// f32::powf (src/node/mix.rs:189), evaluated in f64 and rounded to f32 once.
-// Positive finite base, finite exponent (every pixel of ordinary image data): 2^(b * log2 a) -- the f64
-// log2 / exp2 carry a relative error near 2^-50, |b * log2 a| < 2^11 where the result is finite, so
-// the value rounded to f32 is within 2^-40 relative of exact: the correctly rounded power except
-// when the exact one lies that close to a rounding boundary (then the neighbour; <= 1 ulp either way).
-// Everything else (zero, negative, infinite or NaN base, infinite or NaN exponent) takes the f64 pow
-// routine, whose special-case rules are powf's: pow(x, 0) = 1, pow(1, NaN) = 1, negative base with a
-// non-integer exponent = NaN, signed zeros and infinities by the exponent's parity ...
-static __device__ __noinline__ float kc_powf(float a, float b)
+// f32::powf (src/node/mix.rs:189), evaluated in f64 and rounded to f32 once (<= 1 ulp from any libm powf).
+// Positive finite base and finite exponent -- every pixel of ordinary image data -- take
+// pow_positive() (pow_positive.inc: 2^(b log2 a), ~75 f64 operations; against the f64 pow routine it
+// differs for about 1 pair in 10^8, by one ulp: profiles/pow_check.hip).  Everything else (zero,
+// negative, infinite or NaN base, infinite or NaN exponent) goes to that routine, whose special-case
+// rules are powf's: pow(x, 0) = 1, pow(1, NaN) = 1, negative base with a non-integer exponent = NaN,
+// signed zeros and infinities by the exponent's parity ...
+#include "pow_positive.inc"
+
+static __device__ __noinline__ float pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
+
+static __device__ __forceinline__ float kc_powf(float a, float b)
 {
-    if (a > 0.0f && a < __builtin_inff() && __builtin_fabsf(b) < __builtin_inff())
-        return (float)exp2((double)b * log2((double)a));
-    return (float)pow((double)a, (double)b);
+    if (a > 0.0f && a < __builtin_inff() && __builtin_fabsf(b) < __builtin_inff()) return pow_positive(a, b);
+    return pow_general(a, b);
 }
 
 template <int CODE>
