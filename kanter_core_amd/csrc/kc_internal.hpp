@@ -100,9 +100,14 @@ inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t v_stride,
     if (h_stride > KC_RESIZE_REG_TAPS) n += 2u * tile_w + (size_t)tile_w * h_stride;
     return n * sizeof(float);
 }
-hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
-                             uint32_t dh, TapsDev v, TapsDev h, uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h,
-                             uint32_t ncp, hipStream_t s);
+// Up to 4 planes of equal size (the planes of one image) resampled by one launch, blockIdx.z = plane.
+struct ResizePlanes {
+    const float *src[4];
+    float *dst[4];
+    uint32_t spitch[4], dpitch[4];  // in floats
+};
+hipError_t launch_resize_lds(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
+                             uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);
 // Fused resample + chain: input slot n_in - 1 of the program is produced by the resampler.
 hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);

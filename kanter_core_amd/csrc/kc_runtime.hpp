@@ -152,6 +152,7 @@ int height_to_normal_process(kc_image *in, kc_image **out);
 int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t);
 int resize_image(kc_image *src, kc_size size, int filter, kc_image **out);
 int resize_force(kc_plane *p);  // RESIZE -> MEM through the plain resize kernel
+int resize_force_many(kc_plane *const *planes, int n);  // same; equal resamples share launches
 // Runs a chain whose operands include ONE resampled plane per channel inside the resize kernel
 // (phase 2 feeds the chain program).  *launched = false when the case is not eligible (taps not
 // in registers, tile does not fit LDS, program too long): the caller forces the RESIZE planes.

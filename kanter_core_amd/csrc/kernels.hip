@@ -562,12 +562,13 @@ static __device__ __forceinline__ void resize_out_row(const ResizeCols<MAXT> &C,
 }
 
 template <int MINT, int MAXT>  // horizontal taps, all in registers: MINT unconditional, up to MAXT
-__global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict__ src, uint32_t spitch,
-                                                         float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
-                                                         uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
-                                                         uint32_t tile_h, uint32_t ncp)
+__global__ __launch_bounds__(256) void resize_lds_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
+                                                         TapsDev H, uint32_t tile_w, uint32_t tile_h, uint32_t ncp)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float *__restrict__ src = P.src[blockIdx.z];  // blockIdx.z = plane: up to 4 planes of one image per launch
+    float *__restrict__ dst = P.dst[blockIdx.z];
+    const uint32_t spitch = P.spitch[blockIdx.z], dpitch = P.dpitch[blockIdx.z];
     const uint32_t col_groups = tile_w / 4;         // threads across one tile row
     const uint32_t row_groups = 256u / col_groups;  // tile rows in flight
     const uint32_t cg = threadIdx.x % col_groups;
@@ -602,12 +603,14 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const float *__restrict
 // Wide horizontal windows (more than 8 taps: down-sampling).  The tile's horizontal tap table is
 // staged in LDS behind the vertical one and every thread produces single outputs, four taps per trip
 // (both operands come from LDS; a tap past the window repeats the last one and adds -0.0).
-__global__ __launch_bounds__(256) void resize_wide_kernel(const float *__restrict__ src, uint32_t spitch,
-                                                          float *__restrict__ dst, uint32_t dpitch, uint32_t dw,
-                                                          uint32_t dh, TapsDev V, TapsDev H, uint32_t tile_w,
-                                                          uint32_t tile_h, uint32_t ncp, uint32_t h_off)
+__global__ __launch_bounds__(256) void resize_wide_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
+                                                          TapsDev H, uint32_t tile_w, uint32_t tile_h, uint32_t ncp,
+                                                          uint32_t h_off)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float *__restrict__ src = P.src[blockIdx.z];
+    float *__restrict__ dst = P.dst[blockIdx.z];
+    const uint32_t spitch = P.spitch[blockIdx.z], dpitch = P.dpitch[blockIdx.z];
     const uint32_t x0 = blockIdx.x * tile_w, tw = min(x0 + tile_w, dw) - x0;
     const uint32_t c0 = H.left[x0] & ~3u;
     uint32_t *hl = reinterpret_cast<uint32_t *>(lds + h_off);
@@ -727,12 +730,11 @@ __global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P,
 }
 
 template <int MINT>
-static void launch_resize_lds_t(dim3 grid, size_t lds, hipStream_t s, uint32_t maxt, const float *src, uint32_t spitch,
-                                float *dst, uint32_t dpitch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
-                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp)
+static void launch_resize_lds_t(dim3 grid, size_t lds, hipStream_t s, uint32_t maxt, const ResizePlanes &p, uint32_t dw,
+                                uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp)
 {
 #define KC_RESIZE_LAUNCH(MAXT) \
-    resize_lds_kernel<(MINT <= MAXT ? MINT : MAXT), MAXT><<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp)
+    resize_lds_kernel<(MINT <= MAXT ? MINT : MAXT), MAXT><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp)
     if (maxt <= 1) KC_RESIZE_LAUNCH(1);
     else if (maxt == 2) KC_RESIZE_LAUNCH(2);
     else if (maxt == 3) KC_RESIZE_LAUNCH(3);
@@ -742,21 +744,21 @@ static void launch_resize_lds_t(dim3 grid, size_t lds, hipStream_t s, uint32_t m
 #undef KC_RESIZE_LAUNCH
 }
 
-hipError_t launch_resize_lds(const float *src, uint32_t spitch, float *dst, uint32_t dpitch, uint32_t dw,
-                             uint32_t dh, TapsDev v, TapsDev h, uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h,
-                             uint32_t ncp, hipStream_t s)
+hipError_t launch_resize_lds(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
+                             uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s)
 {
     if (dw == 0 || dh == 0) return hipSuccess;
+    if (batch < 1 || batch > 4) return hipErrorInvalidValue;
     if (tile_w % 4 != 0 || tile_w > 1024 || 256u % (tile_w / 4) != 0 || tile_h > 64) return hipErrorInvalidValue;
     const size_t lds = resize_lds_bytes(tile_h, ncp, v.stride, tile_w, h.stride);
-    dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h);
+    dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h, batch);
     if (h.stride > KC_RESIZE_REG_TAPS)
-        resize_wide_kernel<<<grid, 256, lds, s>>>(src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp,
+        resize_wide_kernel<<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp,
                                                   (uint32_t)(resize_lds_bytes(tile_h, ncp, v.stride, 0, 0) / sizeof(float)));
     else if (h_min_count >= 2)
-        launch_resize_lds_t<2>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp);
+        launch_resize_lds_t<2>(grid, lds, s, h.stride, p, dw, dh, v, h, tile_w, tile_h, ncp);
     else
-        launch_resize_lds_t<1>(grid, lds, s, h.stride, src, spitch, dst, dpitch, dw, dh, v, h, tile_w, tile_h, ncp);
+        launch_resize_lds_t<1>(grid, lds, s, h.stride, p, dw, dh, v, h, tile_w, tile_h, ncp);
     return hipGetLastError();
 }
 

@@ -238,64 +238,106 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
     return t;
 }
 
-// Runs the resample src -> dst (both resident).
-static int resize_run(kc_plane *src, kc_plane *dst, int filter)
+// Runs the resample srcs[i] -> dsts[i] (all resident; equal source sizes, equal target sizes): one
+// launch for the whole batch in the tiled form, two per plane in the two-pass form.
+static int resize_run(kc_plane *const *srcs, kc_plane *const *dsts, int n, int filter)
 {
     Context &c = ctx();
-    const kc_size size{ dst->w, dst->h };
+    const kc_plane *s0 = srcs[0];
+    const kc_size size{ dsts[0]->w, dsts[0]->h };
     TapsEntry *tv = nullptr, *th = nullptr;
-    KC_TRY(get_taps(src->h, size.height, filter, &tv));
-    KC_TRY(get_taps(src->w, size.width, filter, &th));
-    const uint32_t spitch = (uint32_t)(src->pitch / 4), dpitch = (uint32_t)(dst->pitch / 4);
+    KC_TRY(get_taps(s0->h, size.height, filter, &tv));
+    KC_TRY(get_taps(s0->w, size.width, filter, &th));
     // Tiled single pass when a tile's vertical-pass intermediate and tap tables fit in LDS; very wide
     // windows fall back to two passes through an HBM intermediate (KC_RESIZE_MODE=3 forces them).
     if (c.resize_mode != 3) {
         const TileChoice t = choose_tile(*tv, *th, size);
         if (t.ok) {
-            hipError_t e = launch_resize_lds(src->dptr, spitch, dst->dptr, dpitch, size.width, size.height, tv->dev, th->dev,
-                                             th->host.min_count, t.tile_w, t.tile_h, t.ncp, c.stream);
+            ResizePlanes rp{};
+            for (int i = 0; i < n; ++i) {
+                rp.src[i] = srcs[i]->dptr;
+                rp.dst[i] = dsts[i]->dptr;
+                rp.spitch[i] = (uint32_t)(srcs[i]->pitch / 4);
+                rp.dpitch[i] = (uint32_t)(dsts[i]->pitch / 4);
+            }
+            hipError_t e = launch_resize_lds(rp, n, size.width, size.height, tv->dev, th->dev, th->host.min_count, t.tile_w,
+                                             t.tile_h, t.ncp, c.stream);
             if (e != hipSuccess) return hip_fail(e, "launch_resize_lds");
             c.launches++;
             return KC_OK;
         }
     }
-    kc_plane *tmp = nullptr;
-    KC_TRY(plane_new_mem(src->w, size.height, &tmp));
-    const uint32_t tpitch = (uint32_t)(tmp->pitch / 4);
-    hipError_t e = launch_resize_vertical(src->dptr, spitch, src->w, tmp->dptr, tpitch, size.height, tv->dev, c.stream);
-    if (e == hipSuccess)
-        e = launch_resize_horizontal(tmp->dptr, tpitch, dst->dptr, dpitch, size.width, size.height, th->dev, c.stream);
-    plane_release(tmp);
-    if (e != hipSuccess) return hip_fail(e, "launch_resize two-pass");
-    c.launches += 2;
+    for (int i = 0; i < n; ++i) {
+        kc_plane *tmp = nullptr;
+        KC_TRY(plane_new_mem(s0->w, size.height, &tmp));
+        const uint32_t tpitch = (uint32_t)(tmp->pitch / 4);
+        hipError_t e = launch_resize_vertical(srcs[i]->dptr, (uint32_t)(srcs[i]->pitch / 4), s0->w, tmp->dptr, tpitch,
+                                              size.height, tv->dev, c.stream);
+        if (e == hipSuccess)
+            e = launch_resize_horizontal(tmp->dptr, tpitch, dsts[i]->dptr, (uint32_t)(dsts[i]->pitch / 4), size.width,
+                                         size.height, th->dev, c.stream);
+        plane_release(tmp);
+        if (e != hipSuccess) return hip_fail(e, "launch_resize two-pass");
+        c.launches += 2;
+    }
     return KC_OK;
 }
 
-// RESIZE -> MEM through the plain resize kernel.
-int resize_force(kc_plane *p)
+// RESIZE -> MEM through the plain resize kernels.  Planes that resample equally sized sources to the
+// same size with the same filter (the planes of an image) share launches, four at a time.
+int resize_force_many(kc_plane *const *planes, int n)
 {
-    if (p->kind != kc_plane::RESIZE) return KC_OK;
+    std::vector<kc_plane *> todo;
+    for (int i = 0; i < n; ++i) {
+        kc_plane *p = planes[i];
+        if (!p || p->kind != kc_plane::RESIZE) continue;
+        bool dup = false;
+        for (auto *q : todo) dup |= (q == p);
+        if (!dup) todo.push_back(p);
+    }
+    if (todo.empty()) return KC_OK;
     KC_TRY(need_init());
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-    kc_plane *dst = nullptr;
-    KC_TRY(plane_new_mem(p->w, p->h, &dst));
-    int s = resize_run(p->rz_src, dst, p->rz_filter);
-    if (s != KC_OK) {
-        plane_release(dst);
-        return s;
+    std::vector<bool> done(todo.size(), false);
+    for (size_t i = 0; i < todo.size(); ++i) {
+        if (done[i]) continue;
+        kc_plane *group[4], *srcs[4], *dsts[4] = { nullptr, nullptr, nullptr, nullptr };
+        int g = 0;
+        for (size_t j = i; j < todo.size() && g < 4; ++j) {
+            kc_plane *q = todo[j], *p = todo[i];
+            if (done[j] || q->w != p->w || q->h != p->h || q->rz_filter != p->rz_filter || q->rz_src->w != p->rz_src->w ||
+                q->rz_src->h != p->rz_src->h)
+                continue;
+            group[g] = q;
+            srcs[g] = q->rz_src;
+            done[j] = true;
+            ++g;
+        }
+        int s = KC_OK;
+        for (int k = 0; k < g && s == KC_OK; ++k) s = plane_new_mem(group[k]->w, group[k]->h, &dsts[k]);
+        if (s == KC_OK) s = resize_run(srcs, dsts, g, group[0]->rz_filter);
+        if (s != KC_OK) {
+            for (int k = 0; k < g; ++k) plane_release(dsts[k]);
+            return s;
+        }
+        for (int k = 0; k < g; ++k) {
+            kc_plane *p = group[k], *dst = dsts[k];
+            p->kind = kc_plane::MEM;
+            p->dptr = dst->dptr;
+            p->pitch = dst->pitch;
+            p->bytes = dst->bytes;
+            p->owned = true;
+            dst->owned = false;
+            dst->dptr = nullptr;
+            plane_release(dst);
+            plane_release(p->rz_src);
+            p->rz_src = nullptr;
+        }
     }
-    p->kind = kc_plane::MEM;
-    p->dptr = dst->dptr;
-    p->pitch = dst->pitch;
-    p->bytes = dst->bytes;
-    p->owned = true;
-    dst->owned = false;
-    dst->dptr = nullptr;
-    plane_release(dst);
-    plane_release(p->rz_src);
-    p->rz_src = nullptr;
     return KC_OK;
 }
+
+int resize_force(kc_plane *p) { return resize_force_many(&p, 1); }
 
 // Fused resample + chain (see kc_runtime.hpp).  Eligible: every channel's resampled operand uses
 // the same tap tables (same source size and filter), at most 4 horizontal taps (held in
@@ -321,7 +363,6 @@ int chain_resize_launch(const ChainProgram &P, int batch, int mode, kc_plane *co
 
 static int resize_plane_uncached(kc_plane *src, kc_size size, int filter, kc_plane **out)
 {
-    Context &c = ctx();
     // A 1x1 source has a single tap whose normalised weight is w/w = 1, in both passes:
     // t = 0.0 + v*1.0 (vertical), u = 0.0 + t*1.0 then clamp (horizontal) -- a constant plane.
     if (src->w == 1 && src->h == 1 && src->kind == kc_plane::CONST) {
@@ -341,7 +382,7 @@ static int resize_plane_uncached(kc_plane *src, kc_size size, int filter, kc_pla
     KC_TRY(need_init());
     KC_TRY(plane_materialize(src));
     // Deferred: a Mix chain that consumes the result resamples inside its own kernel; any other
-    // consumer (or fusion switched off) runs the resize kernel on first use.
+    // consumer runs the resize kernel on first use (with fusion switched off, resize_image does).
     kc_plane *p = new kc_plane();
     p->w = size.width;
     p->h = size.height;
@@ -350,14 +391,6 @@ static int resize_plane_uncached(kc_plane *src, kc_size size, int filter, kc_pla
     p->rz_filter = filter;
     plane_retain(src);
     *out = p;
-    if (!c.fusion) {
-        int s = resize_force(p);
-        if (s != KC_OK) {
-            plane_release(p);
-            *out = nullptr;
-            return s;
-        }
-    }
     return KC_OK;
 }
 
@@ -381,6 +414,7 @@ int resize_image(kc_image *src, kc_size size, int filter, kc_image **out)
             }
         if (!p[i]) s = resize_plane(src->planes[i], size, filter, &p[i]);
     }
+    if (s == KC_OK && !ctx().fusion) s = resize_force_many(p, src->n);  // one launch for the image's planes
     if (s == KC_OK) *out = image_new(src->n, p);
     for (int i = 0; i < src->n; ++i) plane_release(p[i]);
     return s;

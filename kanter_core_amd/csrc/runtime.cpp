@@ -307,7 +307,7 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
             for (auto *o : outs) plane_release(o);
             if (s != KC_OK) return s;
             // not eligible: run the resamples on their own, the caller rebuilds the program
-            for (int b = 0; b < batch; ++b) KC_TRY(resize_force(bc.sampled[b]));
+            KC_TRY(resize_force_many(bc.sampled, batch));
             return KC_RETRY_CHAIN;
         }
     }
@@ -352,10 +352,10 @@ int planes_force(kc_plane *const *planes, int n)
 {
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
     std::vector<kc_plane *> todo;
+    KC_TRY(resize_force_many(planes, n));
     for (int i = 0; i < n; ++i) {
         kc_plane *p = planes[i];
         if (!p) continue;
-        if (p->kind == kc_plane::RESIZE) KC_TRY(resize_force(p));
         if (p->kind != kc_plane::LAZY) continue;
         bool dup = false;
         for (auto *q : todo) dup |= (q == p);

@@ -161,6 +161,30 @@ def test_resize_bit_exact_many_tiles(kc, orc, filt, src, dst):
     assert bit_equal(got, want), "%s %s->%s max ulp %s" % (filt, src, dst, max_ulp(got, want))
 
 
+@pytest.mark.parametrize("fusion", [True, False])
+def test_resize_rgba_planes_share_one_launch(kc, orc, fusion):
+    """The planes of an image are resampled by one launch (blockIdx.z = plane); aliased planes once."""
+    h, w = 40, 52
+    a = synthetic_rgba(SEED_A, h, w)
+    kc.set_fusion(fusion)
+    try:
+        l0 = kc.stats()["kernel_launches"]
+        got = kc.resize_image(kc.SlotImage.from_planes(a), (130, 100), kc.ResizeFilter.CatmullRom).planes()
+        l1 = kc.stats()["kernel_launches"]
+        gray = kc.SlotImage.from_planes([a[0]]).as_type(True)  # [p, p, p, ones]
+        got_g = kc.resize_image(gray, (130, 100)).planes()
+        l2 = kc.stats()["kernel_launches"]
+    finally:
+        kc.set_fusion(True)
+    assert_planes(got, [orc.resize_plane(p, 130, 100, "CatmullRom") for p in a], what="rgba resize")
+    assert l1 - l0 == 1
+    want = orc.resize_plane(a[0], 130, 100, "Triangle")
+    assert_planes(got_g, [want, want, want, np.ones((100, 130), np.float32)], what="aliased planes")
+    # p once; the ones plane is resampled like any other plane (sum of f32 weights, as the reference
+    # does): one fill to make it resident, then ONE launch for both
+    assert l2 - l1 == 2
+
+
 def test_resize_two_pass_fallback_matches(kc, orc):
     # a down-sampling window too wide for the smallest LDS tile (about 4096 source columns per output)
     p = splitmix_plane(SEED_B, 1, 8, 8192)
