@@ -35,6 +35,7 @@ def main():
     A, B = kc.SlotImage.from_planes(a), kc.SlotImage.from_planes(b)
     Ag, Bg = kc.SlotImage.from_planes(a[:1]), kc.SlotImage.from_planes(b[:1])
     small = kc.SlotImage.from_planes([splitmix_plane(SEED_B, 0, S // 8, S // 8)])
+    small4 = kc.SlotImage.from_planes([splitmix_plane(SEED_B, c, S // 8, S // 8) for c in range(4)])
     white = kc.combine_rgba_process([kc.value_process(1.0)] * 3 + [None])
     u8 = np.random.default_rng(1).integers(0, 256, (S, S, 4), dtype=np.uint8)
     kc.set_fusion(False)  # every operator call launches its kernel immediately
@@ -60,6 +61,7 @@ def main():
         "as_type rgba->gray (chain_kernel<3,4,1>)": (lambda: A.as_type(False), 16 * px),
         "fill (fill_kernel)": (lambda: kc.SlotImage.from_value((S, S), 0.5, False).materialize(), 4 * px),
         "resize 512->4096 triangle, 1 plane (resize_lds_kernel<2,3>)": (lambda: kc.resize_image(small, (S, S)), 4 * px * (1 + 1 / 64.0)),
+        "resize 512->4096 triangle, 4 planes in one launch": (lambda: kc.resize_image(small4, (S, S)), 16 * px * (1 + 1 / 64.0)),
         "resize 4096->512 triangle, 1 plane": (lambda: kc.resize_image(Ag, (S // 8, S // 8)), 4 * px * (1 + 1 / 64.0)),
         "resize 512->4096 lanczos3, 1 plane": (lambda: kc.resize_image(small, (S, S), kc.ResizeFilter.Lanczos3), 4 * px * (1 + 1 / 64.0)),
         "height_to_normal (height_to_normal_kernel)": (lambda: kc.height_to_normal_process(Ag), 16 * px),
