@@ -374,6 +374,19 @@ def main():
                       "sequentially, as the reference's one-thread-per-node engine runs a linear chain" % (reps, N, S, S, cpu_s),
             "host_cores_available": os.cpu_count(),
         }
+        # the same loops, rows split over the host cores of this GPU's share of the box (SURVEY 8(d) ii)
+        threads = max(1, min(os.cpu_count() or 1, 16))
+        if threads > 1:
+            orc.set_threads(threads)
+            orc.chain32(host_a, host_b, N)  # first touch / thread start-up
+            t0 = time.perf_counter()
+            for _ in range(3):
+                orc.chain32(host_a, host_b, N)
+            mt_s = time.perf_counter() - t0
+            orc.set_threads(1)
+            out["cpu_baseline_all_cores"] = {"value": round(float(N) * S * S * 3 / mt_s / 1e6, 2), "unit": "Mpix/s",
+                                             "cores": threads, "kind": "port",
+                                             "sample": "3 evaluations, rows split over %d OpenMP threads (%.1f s)" % (threads, mt_s)}
         # parity of the timed workload against the oracle, on the same inputs
         got = g[0].slot_data(g[3], 0).image.planes()
         mism = int(sum((x.view(np.uint32) != y.view(np.uint32)).sum() for x, y in zip(got, ref)))
