@@ -44,6 +44,9 @@ struct ChainStepRec {
     uint32_t word;
     float c;
 };
+struct alignas(16) ChainStepPair {  // steps 2i and 2i + 1: one 16-byte scalar load
+    ChainStepRec a, b;
+};
 
 struct ChainProgram {
     uint32_t n_ops;
@@ -59,9 +62,9 @@ struct ChainProgram {
     // resize_chain_kernel only: the source plane of the resampled operand (input slot n_in - 1)
     const float *samp_src[KC_CHAIN_MAX_BATCH];
     uint32_t samp_pitch[KC_CHAIN_MAX_BATCH];  // in floats
-    // One 8-byte record per step and channel so the decode is a single scalar (SMEM) load; one
-    // spare record lets the loop prefetch step i + 1 unconditionally.
-    ChainStepRec step[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_OPS + 1];
+    // One 8-byte record per step and channel, fetched two at a time by one scalar (SMEM) load; one
+    // spare pair lets the loop prefetch the next pair unconditionally.
+    ChainStepPair step[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_OPS / 2 + 1];
 };
 
 // Per-axis tap table of the separable resampler, resident in HBM.

@@ -81,17 +81,19 @@ static __device__ __forceinline__ void apply4c(f4 (&dst)[U], const f4 (&src)[U],
 // scalar path is kept short: one pointer, one s_load_dwordx2 per step, a 2-level switch (operand
 // source, then op), and only the arms the program can contain -- MODE 0 = {+, -, *}, 1 = + divide,
 // 2 = + pow (f64 pow call).  x + acc / x * acc are canonicalised to acc + x / acc * x on the host.
+// The op code sits in bits 0-2 of the step word and is decoded by testing one bit per level (a
+// scalar bit test + branch each): no field extraction, no compare chains.
 #define KC_CODE_SWITCH(APPLY, DST, SRC)                                                   \
-    switch (code) {                                                                       \
-    case CH_ADD: APPLY(CH_ADD, DST, SRC); break;                                          \
-    case CH_SUB_L: APPLY(CH_SUB_L, DST, SRC); break;                                      \
-    case CH_SUB_R: APPLY(CH_SUB_R, DST, SRC); break;                                      \
-    case CH_MUL: APPLY(CH_MUL, DST, SRC); break;                                          \
-    case CH_DIV_L: if constexpr (MODE >= 1) { APPLY(CH_DIV_L, DST, SRC); } else __builtin_unreachable(); break; \
-    case CH_DIV_R: if constexpr (MODE >= 1) { APPLY(CH_DIV_R, DST, SRC); } else __builtin_unreachable(); break; \
-    case CH_POW_L: if constexpr (MODE >= 2) { APPLY(CH_POW_L, DST, SRC); } else __builtin_unreachable(); break; \
-    case CH_POW_R: if constexpr (MODE >= 2) { APPLY(CH_POW_R, DST, SRC); } else __builtin_unreachable(); break; \
-    default: __builtin_unreachable();                                                     \
+    if (MODE >= 1 && (w & 4u)) {                                                          \
+        if (MODE >= 2 && (w & 2u)) {                                                      \
+            if (w & 1u) { APPLY(CH_POW_R, DST, SRC); } else { APPLY(CH_POW_L, DST, SRC); } \
+        } else {                                                                          \
+            if (w & 1u) { APPLY(CH_DIV_R, DST, SRC); } else { APPLY(CH_DIV_L, DST, SRC); } \
+        }                                                                                 \
+    } else if (w & 2u) {                                                                  \
+        if (w & 1u) { APPLY(CH_MUL, DST, SRC); } else { APPLY(CH_SUB_R, DST, SRC); }      \
+    } else {                                                                              \
+        if (w & 1u) { APPLY(CH_SUB_L, DST, SRC); } else { APPLY(CH_ADD, DST, SRC); }      \
     }
 
 // Runs the whole step program on the U float4 a thread holds: acc = start, then every step.
@@ -131,36 +133,39 @@ static __device__ __forceinline__ void chain_run(const ChainProgram &P, const ui
     // Steps alternate acc -> alt -> acc (no arm ever merges register sets); the host validates
     // every record, so unknown words cannot occur.
     const uint32_t n_ops = P.n_ops;
-    const ChainStepRec *ps = P.step[b];
-    ChainStepRec s_next = ps[0];
+    const ChainStepPair *pp = P.step[b];  // two records per 16-byte scalar load, fetched one pair ahead
+    ChainStepPair nxt = pp[0];
     f4 alt[U];
 #define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, U>(DST, SRC, c)
 #define KC_APPLY_0(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[0])
 #define KC_APPLY_1(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0])
 #define KC_APPLY_2(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0])
 #define KC_APPLY_3(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0])
-#define KC_STEP(DST, SRC, IDX)                                                          \
+    // operand source in bits 8-10: 0 = the constant, k + 1 = input plane k; again one bit per level
+#define KC_STEP(DST, SRC, REC)                                                          \
     {                                                                                   \
-        const uint32_t code = s_next.word & 0xffu;                                      \
-        const uint32_t srcsel = s_next.word >> 8;                                       \
-        const float c = s_next.c;                                                       \
-        s_next = ps[(IDX) + 1];                                                         \
-        switch (srcsel) {                                                               \
-        case 0: KC_CODE_SWITCH(KC_APPLY_C, DST, SRC) break;                             \
-        case 1: KC_CODE_SWITCH(KC_APPLY_0, DST, SRC) break;                             \
-        case 2: if constexpr (K > 1) { KC_CODE_SWITCH(KC_APPLY_1, DST, SRC) } else __builtin_unreachable(); break; \
-        case 3: if constexpr (K > 2) { KC_CODE_SWITCH(KC_APPLY_2, DST, SRC) } else __builtin_unreachable(); break; \
-        case 4: if constexpr (K > 3) { KC_CODE_SWITCH(KC_APPLY_3, DST, SRC) } else __builtin_unreachable(); break; \
-        default: __builtin_unreachable();                                               \
+        const uint32_t w = (REC).word;                                                  \
+        const float c = (REC).c;                                                        \
+        if (w & 0x100u) {                                                               \
+            if (K > 2 && (w & 0x200u)) { KC_CODE_SWITCH(KC_APPLY_2, DST, SRC) }         \
+            else { KC_CODE_SWITCH(KC_APPLY_0, DST, SRC) }                               \
+        } else if (K > 1 && (w & 0x200u)) {                                             \
+            KC_CODE_SWITCH(KC_APPLY_1, DST, SRC)                                        \
+        } else if (K > 3 && (w & 0x400u)) {                                             \
+            KC_CODE_SWITCH(KC_APPLY_3, DST, SRC)                                        \
+        } else {                                                                        \
+            KC_CODE_SWITCH(KC_APPLY_C, DST, SRC)                                        \
         }                                                                               \
     }
     uint32_t i = 0;
     for (; i + 1 < n_ops; i += 2) {
-        KC_STEP(alt, acc, i)
-        KC_STEP(acc, alt, i + 1)
+        const ChainStepPair cur = nxt;
+        nxt = pp[i / 2 + 1];
+        KC_STEP(alt, acc, cur.a)
+        KC_STEP(acc, alt, cur.b)
     }
     if (i < n_ops) {
-        KC_STEP(alt, acc, i)
+        KC_STEP(alt, acc, nxt.a)
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = alt[u];
     }
@@ -236,8 +241,9 @@ __global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
     f4 acc[1];
     acc[0] = f4{ P.start_c[b], P.start_c[b], P.start_c[b], P.start_c[b] };
     for (uint32_t i = 0; i < P.n_ops; ++i) {
-        const uint32_t code = P.step[b][i].word & 0xffu;
-        const float c = P.step[b][i].c;
+        const ChainStepRec r = (i & 1u) ? P.step[b][i / 2].b : P.step[b][i / 2].a;
+        const uint32_t w = r.word;
+        const float c = r.c;
         f4 nxt[1];
 #define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, 1>(DST, SRC, c)
         KC_CODE_SWITCH(KC_APPLY_C, nxt, acc)

@@ -232,15 +232,16 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
         if (code == CH_ADD_R) code = CH_ADD;  // commutative: the same IEEE result
         if (code == CH_MUL_R) code = CH_MUL;
         const uint32_t word = chain_op_word(code, src);
+        auto rec = [&](int ch_) -> ChainStepRec & { return (i & 1) ? P.step[ch_][i / 2].b : P.step[ch_][i / 2].a; };
         if (b == 0) {
-            P.step[0][i].word = word;
+            rec(0).word = word;
             if (code == CH_DIV_L || code == CH_DIV_R) bc.mode = bc.mode < 1 ? 1 : bc.mode;
             if (code == CH_POW_L || code == CH_POW_R) bc.mode = 2;
-        } else if (P.step[0][i].word != word) {
+        } else if (rec(0).word != word) {
             return false;
         }
-        P.step[b][i].word = word;
-        P.step[b][i].c = c;
+        rec(b).word = word;
+        rec(b).c = c;
     }
     const uint32_t n_in = (uint32_t)km + (samp ? 1u : 0u);
     if (b == 0)
