@@ -386,7 +386,7 @@ def main():
             orc.set_threads(1)
             out["cpu_baseline_all_cores"] = {"value": round(float(N) * S * S * 3 / mt_s / 1e6, 2), "unit": "Mpix/s",
                                              "cores": threads, "kind": "port",
-                                             "sample": "3 evaluations, rows split over %d OpenMP threads (%.1f s)" % (threads, mt_s)}
+                                             "sample": "3 evaluations, rows split over %d OpenMP threads = one GPU's share of the box's %d host cores (%.1f s)" % (threads, os.cpu_count() or 1, mt_s)}
         # parity of the timed workload against the oracle, on the same inputs
         got = g[0].slot_data(g[3], 0).image.planes()
         mism = int(sum((x.view(np.uint32) != y.view(np.uint32)).sum() for x, y in zip(got, ref)))
