@@ -46,6 +46,28 @@ __global__ __launch_bounds__(256) void add_y(Args p)
     }
 }
 
+// U float4 per lane, the U chunks of a block spread over the plane (chunk u at u * n4 / U + block * 256)
+template <int U>
+__global__ __launch_bounds__(256) void add_spread(Args p)
+{
+    const int ch = blockIdx.y;
+    const float4 *__restrict__ a = p.a[ch];
+    const float4 *__restrict__ b = p.b[ch];
+    float4 *__restrict__ o = p.o[ch];
+    const uint32_t part = p.n4 / U;
+    const uint32_t base = blockIdx.x * 256u + threadIdx.x;
+    float4 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x[u] = a[base + u * part];
+#pragma unroll
+    for (int u = 0; u < U; ++u) y[u] = b[base + u * part];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float4 r = { x[u].x + y[u].x, x[u].y + y[u].y, x[u].z + y[u].z, x[u].w + y[u].w };
+        o[base + u * part] = r;
+    }
+}
+
 // same, but one block does all three channels of its pixel range (9 streams per block)
 template <int U>
 __global__ __launch_bounds__(256) void add_3ch(Args p)
@@ -174,12 +196,13 @@ int main()
         double t2 = timed(s, reps, [&] { add_y<2><<<dim3(n4 / 512, 3), 256, 0, s>>>(p); });
         double t4 = timed(s, reps, [&] { add_y<4><<<dim3(n4 / 1024, 3), 256, 0, s>>>(p); });
         double t8 = timed(s, reps, [&] { add_y<8><<<dim3(n4 / 2048, 3), 256, 0, s>>>(p); });
+        double tsp = timed(s, reps, [&] { add_spread<4><<<dim3(n4 / 1024, 3), 256, 0, s>>>(p); });
         double t3c = timed(s, reps, [&] { add_3ch<2><<<n4 / 512, 256, 0, s>>>(p); });
         double t3c4 = timed(s, reps, [&] { add_3ch<4><<<n4 / 1024, 256, 0, s>>>(p); });
         double tp = timed(s, reps, [&] { add_persist<4><<<256 * 8, 256, 0, s>>>(p, n4 / 1024); });
         double tp2 = timed(s, reps, [&] { add_persist<4><<<256 * 4, 256, 0, s>>>(p, n4 / 1024); });
-        std::printf("skew %8zu: y/U1 %6.1f  y/U2 %6.1f  y/U4 %6.1f  y/U8 %6.1f  3ch/U2 %6.1f  3ch/U4 %6.1f  persist8 %6.1f  persist4 %6.1f us  (best %.2f TB/s)\n",
-                    skew, t1 * 1e6, t2 * 1e6, t4 * 1e6, t8 * 1e6, t3c * 1e6, t3c4 * 1e6, tp * 1e6, tp2 * 1e6,
+        std::printf("skew %8zu: y/U1 %6.1f  y/U2 %6.1f  y/U4 %6.1f  spread/U4 %6.1f  y/U8 %6.1f  3ch/U2 %6.1f  3ch/U4 %6.1f  persist8 %6.1f  persist4 %6.1f us  (best %.2f TB/s)\n",
+                    skew, t1 * 1e6, t2 * 1e6, t4 * 1e6, tsp * 1e6, t8 * 1e6, t3c * 1e6, t3c4 * 1e6, tp * 1e6, tp2 * 1e6,
                     bytes9 / std::min({ t1, t2, t4, t8, t3c, t3c4, tp, tp2 }) / 1e12);
     }
     CK(hipFree(buf));
