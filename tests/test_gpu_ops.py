@@ -185,13 +185,16 @@ def test_resize_rgba_planes_share_one_launch(kc, orc, fusion):
     assert l2 - l1 == 2
 
 
-def test_resize_two_pass_fallback_matches(kc, orc):
-    # a down-sampling window too wide for the smallest LDS tile (about 4096 source columns per output)
-    p = splitmix_plane(SEED_B, 1, 8, 8192)
+@pytest.mark.parametrize("src,dst", [((8192, 8), (12, 5)), ((8, 8192), (5, 12)), ((3000, 3000), (2, 2))])
+def test_resize_two_pass_fallback_matches(kc, orc, src, dst):
+    # down-sampling windows (about 4096 source columns / rows per output) too large for the smallest
+    # LDS tile, horizontally, vertically and both: the vertical + horizontal kernels run instead
+    (sw, sh), (dw, dh) = src, dst
+    p = splitmix_plane(SEED_B, 1, sh, sw)
     l0 = kc.stats()["kernel_launches"]
-    got = kc.resize_image(kc.SlotImage.from_planes([p]), (12, 5), kc.ResizeFilter.Lanczos3).planes()[0]
+    got = kc.resize_image(kc.SlotImage.from_planes([p]), (dw, dh), kc.ResizeFilter.Lanczos3).planes()[0]
     assert kc.stats()["kernel_launches"] - l0 == 2, "expected the vertical + horizontal kernels"
-    assert bit_equal(got, orc.resize_plane(p, 12, 5, "Lanczos3"))
+    assert bit_equal(got, orc.resize_plane(p, dw, dh, "Lanczos3"))
 
 
 def test_resize_source_in_wrapped_memory_with_tight_pitch(kc, orc):
