@@ -1,0 +1,23 @@
+#!/bin/bash
+# Runs the CPU-side tests of the product library with its HOST code (runtime, graph, JSON, PNG, C API)
+# built under AddressSanitizer + UndefinedBehaviorSanitizer.  Device code is the regular build: GPU
+# sanitizers are not available on the target pool.  Restores the regular library afterwards.
+set -e
+cd "$(dirname "$0")/.."
+CL=/opt/rocm/lib/llvm/bin/clang++
+OUT=/tmp/kc_asan
+mkdir -p $OUT
+python -m kanter_core_amd.build >/dev/null
+for f in runtime ops resize graph json png c_api; do
+  $CL -x c++ -O1 -g -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer \
+      -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Ikanter_core_amd/csrc -c kanter_core_amd/csrc/$f.cpp -o $OUT/$f.o &
+done
+wait
+$CL -shared -fPIC -fsanitize=address,undefined -shared-libsan -o $OUT/libkanter_core_amd.so kanter_core_amd/csrc/build/kernels.o \
+    $OUT/{runtime,ops,resize,graph,json,png,c_api}.o -L/opt/rocm/lib -lamdhip64 -lz -Wl,-rpath,/opt/rocm/lib
+cp kanter_core_amd/libkanter_core_amd.so $OUT/regular.so
+cp $OUT/libkanter_core_amd.so kanter_core_amd/libkanter_core_amd.so
+trap 'cp $OUT/regular.so kanter_core_amd/libkanter_core_amd.so' EXIT
+RT=$($CL -print-file-name=libclang_rt.asan-x86_64.so)
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+    python -m pytest tests/test_host_graph.py tests/test_cabi_symbols.py tests/test_multi_gpu_gloo.py -x -q "$@"
