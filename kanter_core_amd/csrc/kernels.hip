@@ -394,13 +394,11 @@ hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *ds
 }
 
 // Single-pass tiled form: each workgroup owns a tile_h x tile_w output tile.
-//   phase 1 vertical pass HBM -> LDS: a wave takes one tile row at a time; its lanes own consecutive
-//           4-column groups of the tile's source window and read the source rows of that output
-//           row with 16-byte loads (one contiguous run per row and wave).  Rows shared by
-//           neighbouring output rows are re-read through L1/L2, not HBM.  The row's weights are
-//           fetched with one coalesced load and handed out lane by lane (v_readlane), so the
-//           inner loop is load + multiply + add.  The intermediate the two-pass form would write
-//           to HBM (tile_h x ncp floats) never leaves the CU;
+//   phase 1 vertical pass HBM -> LDS: (tile row, 4-column group) items dealt out to all lanes; a
+//           lane reads its item's source rows with 16-byte loads, several in flight, weights from
+//           the LDS copy of the tile rows' tap table (resize_vpass_items).  Rows shared by
+//           neighbouring output rows are re-read through L1/L2, not HBM.  The intermediate the
+//           two-pass form would write to HBM (tile_h x ncp floats) never leaves the CU;
 //   phase 2 horizontal pass out of LDS: every thread owns 4 consecutive output columns for the
 //           whole tile, so its tap windows and weights sit in registers and the
 //           four results leave as one 16-byte store -- or, in resize_chain_kernel, feed the Mix
@@ -459,7 +457,7 @@ static __device__ __forceinline__ void resize_vpass_items(const f4 *__restrict__
         a.w += px.w * wt;
     };
     const uint32_t items = th * nq;
-    // i / nq by multiply-high: exact here because i < 64 * 256 (tile_h <= 64, 64 KiB of LDS)
+    // i / nq by multiply-high: exact here because i < th * nq <= 4096 (16 bytes of LDS per item, 64 KiB)
     const uint32_t nq_magic = nq > 1 ? 0xFFFFFFFFu / nq + 1u : 0u;
     for (uint32_t i = threadIdx.x; i < items; i += 256u) {
         const uint32_t ty = nq > 1 ? __umulhi(i, nq_magic) : i;
