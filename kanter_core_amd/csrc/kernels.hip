@@ -78,22 +78,20 @@ static __device__ __forceinline__ void apply4c(f4 (&dst)[U], const f4 (&src)[U],
 // SMEM one step ahead), so the dispatch is scalar compares and branches and each arm is
 // straight-line VALU on the U float4 the thread owns.  PMC shows the kernel is ISSUE-bound for
 // long chains (every instruction, scalar or vector, costs the wave ~4 issue cycles), so the
-// scalar path is kept short: one pointer, one s_load_dwordx2 per step, a 2-level switch (operand
+// scalar path is kept short: one 16-byte scalar load per two steps, a 2-level switch (operand
 // source, then op), and only the arms the program can contain -- MODE 0 = {+, -, *}, 1 = + divide,
 // 2 = + pow (f64 pow call).  x + acc / x * acc are canonicalised to acc + x / acc * x on the host.
-// The op code sits in bits 0-2 of the step word and is decoded by testing one bit per level (a
-// scalar bit test + branch each): no field extraction, no compare chains.
 #define KC_CODE_SWITCH(APPLY, DST, SRC)                                                   \
-    if (MODE >= 1 && (w & 4u)) {                                                          \
-        if (MODE >= 2 && (w & 2u)) {                                                      \
-            if (w & 1u) { APPLY(CH_POW_R, DST, SRC); } else { APPLY(CH_POW_L, DST, SRC); } \
-        } else {                                                                          \
-            if (w & 1u) { APPLY(CH_DIV_R, DST, SRC); } else { APPLY(CH_DIV_L, DST, SRC); } \
-        }                                                                                 \
-    } else if (w & 2u) {                                                                  \
-        if (w & 1u) { APPLY(CH_MUL, DST, SRC); } else { APPLY(CH_SUB_R, DST, SRC); }      \
-    } else {                                                                              \
-        if (w & 1u) { APPLY(CH_SUB_L, DST, SRC); } else { APPLY(CH_ADD, DST, SRC); }      \
+    switch (w & 0xffu) {                                                                  \
+    case CH_ADD: APPLY(CH_ADD, DST, SRC); break;                                          \
+    case CH_SUB_L: APPLY(CH_SUB_L, DST, SRC); break;                                      \
+    case CH_SUB_R: APPLY(CH_SUB_R, DST, SRC); break;                                      \
+    case CH_MUL: APPLY(CH_MUL, DST, SRC); break;                                          \
+    case CH_DIV_L: if constexpr (MODE >= 1) { APPLY(CH_DIV_L, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_DIV_R: if constexpr (MODE >= 1) { APPLY(CH_DIV_R, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_POW_L: if constexpr (MODE >= 2) { APPLY(CH_POW_L, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_POW_R: if constexpr (MODE >= 2) { APPLY(CH_POW_R, DST, SRC); } else __builtin_unreachable(); break; \
+    default: __builtin_unreachable();                                                     \
     }
 
 // Runs the whole step program on the U float4 a thread holds: acc = start, then every step.
@@ -141,20 +139,17 @@ static __device__ __forceinline__ void chain_run(const ChainProgram &P, const ui
 #define KC_APPLY_1(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0])
 #define KC_APPLY_2(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0])
 #define KC_APPLY_3(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0])
-    // operand source in bits 8-10: 0 = the constant, k + 1 = input plane k; again one bit per level
 #define KC_STEP(DST, SRC, REC)                                                          \
     {                                                                                   \
         const uint32_t w = (REC).word;                                                  \
         const float c = (REC).c;                                                        \
-        if (w & 0x100u) {                                                               \
-            if (K > 2 && (w & 0x200u)) { KC_CODE_SWITCH(KC_APPLY_2, DST, SRC) }         \
-            else { KC_CODE_SWITCH(KC_APPLY_0, DST, SRC) }                               \
-        } else if (K > 1 && (w & 0x200u)) {                                             \
-            KC_CODE_SWITCH(KC_APPLY_1, DST, SRC)                                        \
-        } else if (K > 3 && (w & 0x400u)) {                                             \
-            KC_CODE_SWITCH(KC_APPLY_3, DST, SRC)                                        \
-        } else {                                                                        \
-            KC_CODE_SWITCH(KC_APPLY_C, DST, SRC)                                        \
+        switch (w >> 8) {                                                               \
+        case 0: KC_CODE_SWITCH(KC_APPLY_C, DST, SRC) break;                             \
+        case 1: KC_CODE_SWITCH(KC_APPLY_0, DST, SRC) break;                             \
+        case 2: if constexpr (K > 1) { KC_CODE_SWITCH(KC_APPLY_1, DST, SRC) } else __builtin_unreachable(); break; \
+        case 3: if constexpr (K > 2) { KC_CODE_SWITCH(KC_APPLY_2, DST, SRC) } else __builtin_unreachable(); break; \
+        case 4: if constexpr (K > 3) { KC_CODE_SWITCH(KC_APPLY_3, DST, SRC) } else __builtin_unreachable(); break; \
+        default: __builtin_unreachable();                                               \
         }                                                                               \
     }
     uint32_t i = 0;

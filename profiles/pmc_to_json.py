@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Folds the rocprofv3 --pmc passes of profiles/run_pmc.sh into profiles/pmc_chain_kernel.json:
+    python profiles/pmc_to_json.py gpurun_out/pmc  [out.json]
+Averages every counter over the timed dispatches of the dominant kernel (warm-up dispatches dropped) and applies
+the gfx950 corrections of MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE count KiB; wide coalesced
+reads are under-reported by 2x (FETCH_SIZE doubled); 16-byte stores are counted exactly."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src = sys.argv[1]
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_chain_kernel.json")
+per = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> counter -> dispatch -> value
+for f in glob.glob(os.path.join(src, "pass*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        d = per[r["Kernel_Name"]][r["Counter_Name"]]
+        d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+kernel = max((k for k in per if "chain_kernel" in k), key=lambda k: len(per[k].get("WRITE_SIZE", {})))
+avg = {}
+for c, d in sorted(per[kernel].items()):
+    ids = sorted(d)[3:]  # bench.py --warmup 3
+    avg[c] = sum(d[i] for i in ids) / len(ids)
+fetch = avg["FETCH_SIZE"] * 1024.0 * 2.0
+write = avg["WRITE_SIZE"] * 1024.0
+json.dump({
+    "kernel": kernel.split("(")[0].replace("void ", ""),
+    "workload": "bench.py default (32-node chain, 4096x4096 f32x4), warm-up dispatches dropped",
+    "counters_avg_per_launch": {k: round(v, 1) for k, v in avg.items()},
+    "fetch_bytes_corrected_x2": fetch,
+    "write_bytes": write,
+    "hbm_bytes_per_launch": fetch + write,
+    "algorithmic_bytes_per_launch": 603979776,
+    "method": "rocprofv3 --kernel-trace --pmc <one counter group per pass> (profiles/run_pmc.sh); FETCH_SIZE doubled per "
+              "MI355X_MICROARCH.md HBM section; WRITE_SIZE exact for 16-B stores; both in KiB",
+}, open(out, "w"), indent=1)
+print(open(out).read())
