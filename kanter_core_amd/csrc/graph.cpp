@@ -104,18 +104,54 @@ Node node_from_desc(const kc_node_desc &d)
 // ------------------------------------------------------------------------------------------
 // NodeGraph, src/node_graph.rs
 // ------------------------------------------------------------------------------------------
+const GraphIndex &NodeGraph::index() const
+{
+    // sizes are compared as well: a change that forgot touch() still cannot leave a stale index behind
+    // unless it kept both counts
+    if (idx.version != version || idx.n_nodes != nodes.size() || idx.n_edges != edges.size()) {
+        idx.node_pos.clear();
+        idx.in_edges.clear();
+        idx.out_edges.clear();
+        for (size_t i = 0; i < nodes.size(); ++i) idx.node_pos.emplace(nodes[i].node_id, (uint32_t)i);  // first wins, as the scan did
+        for (auto &e : edges) {
+            idx.in_edges[e.input_id].push_back(e);
+            idx.out_edges[e.output_id].push_back(e);
+        }
+        idx.version = version;
+        idx.n_nodes = nodes.size();
+        idx.n_edges = edges.size();
+    }
+    return idx;
+}
+
+static const std::vector<kc_edge> kNoEdges;
+
+const std::vector<kc_edge> &NodeGraph::edges_into(uint32_t id) const
+{
+    const GraphIndex &ix = index();
+    auto it = ix.in_edges.find(id);
+    return it == ix.in_edges.end() ? kNoEdges : it->second;
+}
+
+const std::vector<kc_edge> &NodeGraph::edges_out_of(uint32_t id) const
+{
+    const GraphIndex &ix = index();
+    auto it = ix.out_edges.find(id);
+    return it == ix.out_edges.end() ? kNoEdges : it->second;
+}
+
 const Node *NodeGraph::find(uint32_t id) const
 {
-    for (auto &n : nodes)
-        if (n.node_id == id) return &n;
-    return nullptr;
+    const GraphIndex &ix = index();
+    auto it = ix.node_pos.find(id);
+    return it == ix.node_pos.end() ? nullptr : &nodes[it->second];
 }
 
 Node *NodeGraph::find(uint32_t id)
 {
-    for (auto &n : nodes)
-        if (n.node_id == id) return &n;
-    return nullptr;
+    const GraphIndex &ix = index();
+    auto it = ix.node_pos.find(id);
+    return it == ix.node_pos.end() ? nullptr : &nodes[it->second];
 }
 
 uint32_t NodeGraph::new_id()
@@ -168,6 +204,7 @@ static int add_node_internal(NodeGraph &g, Node n, uint32_t id)
     }
     n.node_id = id;
     g.nodes.push_back(std::move(n));
+    g.touch();
     return KC_OK;
 }
 
@@ -212,6 +249,7 @@ int NodeGraph::try_connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is)
     for (auto &e : edges)
         if (e.input_id == in && e.input_slot == is) return KC_ERR_SLOT_OCCUPIED;
     edges.push_back(kc_edge{ on, in, os, is });
+    touch();
     return KC_OK;
 }
 
@@ -228,6 +266,7 @@ int NodeGraph::connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is)
     for (auto &e : edges)
         if (e.output_id == on && e.input_id == in && e.output_slot == os && e.input_slot == is) return KC_ERR_INVALID_EDGE;
     edges.push_back(kc_edge{ on, in, os, is });
+    touch();
     return KC_OK;
 }
 
@@ -238,6 +277,7 @@ int NodeGraph::remove_edge(kc_edge e)
         if (c.output_id == e.output_id && c.input_id == e.input_id && c.output_slot == e.output_slot && c.input_slot == e.input_slot) {
             if (!find(e.input_id)) return KC_ERR_INVALID_NODE_ID;
             edges.erase(edges.begin() + (long)i);
+            touch();
             return KC_OK;
         }
     }
@@ -252,10 +292,12 @@ int NodeGraph::remove_node(uint32_t id, std::vector<kc_edge> *removed)
         if (edges[i].output_id == id || edges[i].input_id == id) {
             if (removed) removed->push_back(edges[i]);
             edges.erase(edges.begin() + (long)i);
+            touch();
         }
     for (size_t i = 0; i < nodes.size(); ++i)
         if (nodes[i].node_id == id) {
             nodes.erase(nodes.begin() + (long)i);
+            touch();
             break;
         }
     return KC_OK;
@@ -273,6 +315,7 @@ int NodeGraph::disconnect_slot(uint32_t id, int side, uint32_t slot, std::vector
         if (hit) {
             if (removed) removed->insert(removed->begin(), e);
             edges.erase(edges.begin() + (long)i);
+            touch();
             any = true;
         }
     }
@@ -282,8 +325,7 @@ int NodeGraph::disconnect_slot(uint32_t id, int side, uint32_t slot, std::vector
 std::vector<uint32_t> NodeGraph::get_children(uint32_t id) const
 {
     std::vector<uint32_t> c;
-    for (auto &e : edges)
-        if (e.output_id == id) c.push_back(e.input_id);
+    for (auto &e : edges_out_of(id)) c.push_back(e.input_id);
     std::sort(c.begin(), c.end());
     c.erase(std::unique(c.begin(), c.end()), c.end());
     return c;
@@ -303,8 +345,7 @@ std::vector<uint32_t> NodeGraph::get_children_recursive(uint32_t id) const
 std::vector<uint32_t> NodeGraph::get_parents(uint32_t id) const
 {
     std::vector<uint32_t> p;
-    for (auto &e : edges)
-        if (e.input_id == id) p.push_back(e.output_id);
+    for (auto &e : edges_into(id)) p.push_back(e.output_id);
     std::sort(p.begin(), p.end());
     p.erase(std::unique(p.begin(), p.end()), p.end());
     return p;
@@ -755,9 +796,7 @@ int kc_live_graph::process_one(uint32_t id)
     Node node = *np;
     node_state[id] = KC_STATE_PROCESSING;
     // engine.rs:213-218: input edges in insertion order; :261-275: one SlotData per edge
-    std::vector<kc_edge> edges;
-    for (auto &e : g.edges)
-        if (e.input_id == id) edges.push_back(e);
+    const std::vector<kc_edge> edges = g.edges_into(id);  // a copy: processing may touch the graph
     std::vector<SlotData> inputs;
     for (auto &e : edges) {
         const SlotData *sd = find_slot(e.output_id, e.output_slot);
@@ -813,9 +852,7 @@ int kc_live_graph::ensure_clean(uint32_t id, int guard)
     KC_TRY(state_of(id, &st));
     if (st == KC_STATE_CLEAN) return KC_OK;
     // parents first (LiveGraph::get_closest_processable, :279-311, collapsed into a DFS)
-    std::vector<kc_edge> edges;
-    for (auto &e : g.edges)
-        if (e.input_id == id) edges.push_back(e);
+    const std::vector<kc_edge> edges = g.edges_into(id);
     for (auto &e : edges) {
         int pst;
         if (state_of(e.output_id, &pst) != KC_OK) continue;  // parent deleted

@@ -242,6 +242,7 @@ bool graph_from_jval(const JVal &root, NodeGraph &g, int depth)
         Node n;
         if (!node_from_jval(jn, n, depth)) return false;
         g.nodes.push_back(std::move(n));
+        g.touch();
     }
     for (auto &je : edges->arr) {
         kc_edge e;
@@ -249,6 +250,7 @@ bool graph_from_jval(const JVal &root, NodeGraph &g, int depth)
             !as_u32(je.get("output_slot"), &e.output_slot) || !as_u32(je.get("input_slot"), &e.input_slot))
             return false;
         g.edges.push_back(e);
+        g.touch();
     }
     // NodeGraph::from_path, src/node_graph.rs:36-43: counter = max id + 1
     uint32_t mx = 0;

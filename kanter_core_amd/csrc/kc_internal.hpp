@@ -36,7 +36,14 @@ enum ChainCode : uint8_t {
     CH_POW_L = 6,  // acc ^ x
     CH_POW_R = 7,  // x ^ acc
     CH_ADD_R = 8,  // x + acc: host-side only, canonicalised to CH_ADD before launch (same IEEE sum)
-    CH_MUL_R = 9   // x * acc: host-side only, canonicalised to CH_MUL
+    CH_MUL_R = 9,  // x * acc: host-side only, canonicalised to CH_MUL
+    // Device-side only (chain_fill): a {+, -, *} step on a plane operand x followed by an invert-style
+    // step "c - acc" (Mix(Subtract)(constant, .), how every graph spells 1 - x) is ONE record and one
+    // dispatch.  Both roundings happen, in order: the result is that of the two separate steps.
+    CH_ADD_INV = 10,   // c - (acc + x)
+    CH_SUBL_INV = 11,  // c - (acc - x)
+    CH_SUBR_INV = 12,  // c - (x - acc)
+    CH_MUL_INV = 13    // c - (acc * x)
 };
 
 // word: bits 0-7 ChainCode, bits 8-15 operand source (0 = the constant c, k + 1 = input plane k).

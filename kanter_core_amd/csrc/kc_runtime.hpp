@@ -12,6 +12,7 @@
 // ------------------------------------------------------------------------------------------
 namespace kc {
 struct Chain;
+struct ChainLink;
 }
 
 // One channel.  MEM: pitched f32 in HBM.  CONST: broadcast scalar (what the reference holds as
@@ -29,7 +30,8 @@ struct kc_plane {
     size_t bytes = 0;  // pool block size (owned planes)
     bool owned = false;
     float cval = 0.0f;
-    kc::Chain *chain = nullptr;
+    kc::ChainLink *link = nullptr;  // LAZY: the last step and what it continues (see ChainLink)
+    kc::Chain *chain = nullptr;     // LAZY: the flattened program, built when the plane is forced
     kc_plane *rz_src = nullptr;  // retained; MEM
     int rz_filter = 0;
 };
@@ -52,9 +54,23 @@ struct ChainStep {
 };
 
 struct Chain {
-    kc_plane *start = nullptr;  // retained; MEM or CONST
+    kc_plane *start = nullptr;  // retained; MEM, CONST or RESIZE
     std::vector<ChainStep> steps;
     ~Chain();
+};
+
+// A lazy plane is "the plane it continues, plus one step": extending a chain is O(1) and consumers of
+// the same prefix share it (a 64-node linear graph used to copy 3 x 64 x 32 steps per evaluation).
+// The flat Chain is built from the links when the plane is forced; a `prev` that has been forced in
+// the meantime is resident and simply becomes the start.
+struct ChainLink {
+    kc_plane *prev = nullptr;   // retained; the LAZY plane continued, or nullptr
+    kc_plane *start = nullptr;  // retained; the chain's first value when prev == nullptr
+    ChainStep step{};           // operand retained
+    uint32_t length = 1;        // steps up to and including this one (an upper bound once a prev was forced)
+    int n_in = 0;               // distinct MEM / RESIZE planes the whole chain reads (same bound)
+    const kc_plane *ins[KC_CHAIN_MAX_IN + 1] = {};
+    ~ChainLink();
 };
 
 struct TapsHost {
@@ -191,10 +207,28 @@ struct Slot {
     int slot_type;
 };
 
+// Look-up tables over NodeGraph::nodes / edges, rebuilt on first use after a change: the evaluator asks
+// "which node is this id", "which edges enter / leave this node" several times per node, and linear
+// scans made an evaluation quadratic in the node count.
+struct GraphIndex {
+    uint64_t version = ~0ull;
+    size_t n_nodes = 0, n_edges = 0;
+    std::unordered_map<uint32_t, uint32_t> node_pos;             // node id -> position in nodes
+    std::unordered_map<uint32_t, std::vector<kc_edge>> in_edges;  // by input_id, in insertion order
+    std::unordered_map<uint32_t, std::vector<kc_edge>> out_edges; // by output_id, in insertion order
+};
+
 struct NodeGraph {
     std::vector<Node> nodes;
     std::vector<kc_edge> edges;
     uint32_t node_id_counter = 0;
+    uint64_t version = 0;      // bumped by every change to nodes / edges (touch())
+    mutable GraphIndex idx;
+
+    void touch() { ++version; }
+    const GraphIndex &index() const;
+    const std::vector<kc_edge> &edges_into(uint32_t id) const;
+    const std::vector<kc_edge> &edges_out_of(uint32_t id) const;
 
     const Node *find(uint32_t id) const;
     Node *find(uint32_t id);

@@ -31,9 +31,13 @@ static __device__ __forceinline__ float kc_powf(float a, float b)
 }
 
 template <int CODE>
-static __device__ __forceinline__ float apply1(float acc, float x)
+static __device__ __forceinline__ float apply1(float acc, float x, float c = 0.0f)
 {
-    if constexpr (CODE == CH_ADD) return acc + x;
+    if constexpr (CODE == CH_ADD_INV) return c - (acc + x);
+    else if constexpr (CODE == CH_SUBL_INV) return c - (acc - x);
+    else if constexpr (CODE == CH_SUBR_INV) return c - (x - acc);
+    else if constexpr (CODE == CH_MUL_INV) return c - (acc * x);
+    else if constexpr (CODE == CH_ADD) return acc + x;
     else if constexpr (CODE == CH_SUB_L) return acc - x;
     else if constexpr (CODE == CH_SUB_R) return x - acc;
     else if constexpr (CODE == CH_MUL) return acc * x;
@@ -51,14 +55,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // loop ping-pongs between two register sets, so no switch arm ever has to preserve or merge the
 // old accumulator and the step costs exactly one packed VALU instruction per pixel pair.
 template <int CODE, int U>
-static __device__ __forceinline__ void apply4(f4 (&dst)[U], const f4 (&src)[U], const f4 (&x)[U])
+static __device__ __forceinline__ void apply4(f4 (&dst)[U], const f4 (&src)[U], const f4 (&x)[U], float c)
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        dst[u].x = apply1<CODE>(src[u].x, x[u].x);
-        dst[u].y = apply1<CODE>(src[u].y, x[u].y);
-        dst[u].z = apply1<CODE>(src[u].z, x[u].z);
-        dst[u].w = apply1<CODE>(src[u].w, x[u].w);
+        dst[u].x = apply1<CODE>(src[u].x, x[u].x, c);
+        dst[u].y = apply1<CODE>(src[u].y, x[u].y, c);
+        dst[u].z = apply1<CODE>(src[u].z, x[u].z, c);
+        dst[u].w = apply1<CODE>(src[u].w, x[u].w, c);
     }
 }
 
@@ -87,6 +91,24 @@ static __device__ __forceinline__ void apply4c(f4 (&dst)[U], const f4 (&src)[U],
     case CH_SUB_L: APPLY(CH_SUB_L, DST, SRC); break;                                      \
     case CH_SUB_R: APPLY(CH_SUB_R, DST, SRC); break;                                      \
     case CH_MUL: APPLY(CH_MUL, DST, SRC); break;                                          \
+    case CH_DIV_L: if constexpr (MODE >= 1) { APPLY(CH_DIV_L, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_DIV_R: if constexpr (MODE >= 1) { APPLY(CH_DIV_R, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_POW_L: if constexpr (MODE >= 2) { APPLY(CH_POW_L, DST, SRC); } else __builtin_unreachable(); break; \
+    case CH_POW_R: if constexpr (MODE >= 2) { APPLY(CH_POW_R, DST, SRC); } else __builtin_unreachable(); break; \
+    default: __builtin_unreachable();                                                     \
+    }
+
+// Plane operands also carry the fused "step, then c - acc" codes.
+#define KC_CODE_SWITCH_P(APPLY, DST, SRC)                                                 \
+    switch (w & 0xffu) {                                                                  \
+    case CH_ADD: APPLY(CH_ADD, DST, SRC); break;                                          \
+    case CH_SUB_L: APPLY(CH_SUB_L, DST, SRC); break;                                      \
+    case CH_SUB_R: APPLY(CH_SUB_R, DST, SRC); break;                                      \
+    case CH_MUL: APPLY(CH_MUL, DST, SRC); break;                                          \
+    case CH_ADD_INV: APPLY(CH_ADD_INV, DST, SRC); break;                                  \
+    case CH_SUBL_INV: APPLY(CH_SUBL_INV, DST, SRC); break;                                \
+    case CH_SUBR_INV: APPLY(CH_SUBR_INV, DST, SRC); break;                                \
+    case CH_MUL_INV: APPLY(CH_MUL_INV, DST, SRC); break;                                  \
     case CH_DIV_L: if constexpr (MODE >= 1) { APPLY(CH_DIV_L, DST, SRC); } else __builtin_unreachable(); break; \
     case CH_DIV_R: if constexpr (MODE >= 1) { APPLY(CH_DIV_R, DST, SRC); } else __builtin_unreachable(); break; \
     case CH_POW_L: if constexpr (MODE >= 2) { APPLY(CH_POW_L, DST, SRC); } else __builtin_unreachable(); break; \
@@ -135,20 +157,20 @@ static __device__ __forceinline__ void chain_run(const ChainProgram &P, const ui
     ChainStepPair nxt = pp[0];
     f4 alt[U];
 #define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, U>(DST, SRC, c)
-#define KC_APPLY_0(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[0])
-#define KC_APPLY_1(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0])
-#define KC_APPLY_2(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0])
-#define KC_APPLY_3(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0])
+#define KC_APPLY_0(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[0], c)
+#define KC_APPLY_1(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0], c)
+#define KC_APPLY_2(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0], c)
+#define KC_APPLY_3(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0], c)
 #define KC_STEP(DST, SRC, REC)                                                          \
     {                                                                                   \
         const uint32_t w = (REC).word;                                                  \
         const float c = (REC).c;                                                        \
         switch (w >> 8) {                                                               \
         case 0: KC_CODE_SWITCH(KC_APPLY_C, DST, SRC) break;                             \
-        case 1: KC_CODE_SWITCH(KC_APPLY_0, DST, SRC) break;                             \
-        case 2: if constexpr (K > 1) { KC_CODE_SWITCH(KC_APPLY_1, DST, SRC) } else __builtin_unreachable(); break; \
-        case 3: if constexpr (K > 2) { KC_CODE_SWITCH(KC_APPLY_2, DST, SRC) } else __builtin_unreachable(); break; \
-        case 4: if constexpr (K > 3) { KC_CODE_SWITCH(KC_APPLY_3, DST, SRC) } else __builtin_unreachable(); break; \
+        case 1: KC_CODE_SWITCH_P(KC_APPLY_0, DST, SRC) break;                           \
+        case 2: if constexpr (K > 1) { KC_CODE_SWITCH_P(KC_APPLY_1, DST, SRC) } else __builtin_unreachable(); break; \
+        case 3: if constexpr (K > 2) { KC_CODE_SWITCH_P(KC_APPLY_2, DST, SRC) } else __builtin_unreachable(); break; \
+        case 4: if constexpr (K > 3) { KC_CODE_SWITCH_P(KC_APPLY_3, DST, SRC) } else __builtin_unreachable(); break; \
         default: __builtin_unreachable();                                               \
         }                                                                               \
     }

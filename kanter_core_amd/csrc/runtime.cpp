@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
+
 #include "kc_runtime.hpp"
 
 namespace kc {
@@ -144,6 +146,7 @@ void plane_release(kc_plane *p)
     if (!p) return;
     if (p->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         if (p->chain) delete p->chain;
+        if (p->link) delete p->link;
         if (p->rz_src) plane_release(p->rz_src);
         if (p->owned && p->dptr) pool_free(p->dptr, p->bytes);
         delete p;
@@ -154,6 +157,64 @@ Chain::~Chain()
 {
     plane_release(start);
     for (auto &s : steps) plane_release(s.operand);
+}
+
+ChainLink::~ChainLink()
+{
+    // Release the prefix iteratively: a long run of otherwise unreferenced lazy planes would recurse
+    // once per plane through plane_release -> ~ChainLink.
+    plane_release(start);
+    plane_release(step.operand);
+    kc_plane *q = prev;
+    prev = nullptr;
+    while (q) {
+        if (q->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) break;  // still referenced elsewhere
+        kc_plane *next = nullptr;
+        if (q->link) {
+            next = q->link->prev;
+            q->link->prev = nullptr;
+        }
+        q->refs.store(1, std::memory_order_relaxed);
+        plane_release(q);  // frees q (its link no longer has a prev)
+        q = next;
+    }
+}
+
+// Identity of a chain input, as input_index() sees it.
+static bool same_input(const kc_plane *a, const kc_plane *b)
+{
+    return a == b || (a->kind == kc_plane::MEM && b->kind == kc_plane::MEM && a->dptr == b->dptr && a->pitch == b->pitch);
+}
+
+static void link_add_input(ChainLink &L, const kc_plane *q)
+{
+    if (q->kind != kc_plane::MEM && q->kind != kc_plane::RESIZE) return;
+    for (int i = 0; i < L.n_in; ++i)
+        if (same_input(L.ins[i], q)) return;
+    if (L.n_in <= KC_CHAIN_MAX_IN) L.ins[L.n_in] = q;
+    L.n_in++;  // may exceed the array: only the count matters beyond KC_CHAIN_MAX_IN
+}
+
+// Builds p->chain (start + steps in order) from the links; planes forced meanwhile end the walk.
+static void chain_flatten(kc_plane *p)
+{
+    if (p->chain) return;
+    Chain *c = new Chain();
+    kc_plane *q = p;
+    for (;;) {
+        ChainLink *L = q->link;
+        c->steps.push_back(L->step);
+        if (L->prev && L->prev->kind == kc_plane::LAZY) {
+            q = L->prev;
+            continue;
+        }
+        c->start = L->prev ? L->prev : L->start;
+        break;
+    }
+    std::reverse(c->steps.begin(), c->steps.end());
+    plane_retain(c->start);
+    for (auto &s : c->steps) plane_retain(s.operand);
+    p->chain = c;
 }
 
 Operand plane_operand(const kc_plane *p)
@@ -217,13 +278,13 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
     if (start_src == -2) start_src = km;
     if (b == 0) {
         std::memset(&P, 0, sizeof(P));
-        P.n_ops = (uint32_t)ch.steps.size();
         P.start_src = start_src;
-    } else if (P.n_ops != ch.steps.size() || P.start_src != start_src) {
+    } else if (P.start_src != start_src) {
         return false;
     }
     P.start_c[b] = c0;
-    for (size_t i = 0; i < ch.steps.size(); ++i) {
+    size_t r = 0;  // records written: a {+, -, *} step on a plane followed by "constant - acc" is one (CH_*_INV)
+    for (size_t i = 0; i < ch.steps.size(); ++i, ++r) {
         const ChainStep &st = ch.steps[i];
         float c = 0.0f;
         int src = slot(st.operand, &c);
@@ -231,18 +292,29 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
         uint8_t code = st.code;
         if (code == CH_ADD_R) code = CH_ADD;  // commutative: the same IEEE result
         if (code == CH_MUL_R) code = CH_MUL;
+        if (src >= 0 && code <= CH_MUL && i + 1 < ch.steps.size() && ch.steps[i + 1].code == CH_SUB_R &&
+            ch.steps[i + 1].operand->kind == kc_plane::CONST) {
+            static const uint8_t inv[4] = { CH_ADD_INV, CH_SUBL_INV, CH_SUBR_INV, CH_MUL_INV };
+            code = inv[code];
+            c = ch.steps[i + 1].operand->cval;
+            ++i;
+        }
         const uint32_t word = chain_op_word(code, src);
-        auto rec = [&](int ch_) -> ChainStepRec & { return (i & 1) ? P.step[ch_][i / 2].b : P.step[ch_][i / 2].a; };
+        auto rec = [&](int ch_) -> ChainStepRec & { return (r & 1) ? P.step[ch_][r / 2].b : P.step[ch_][r / 2].a; };
         if (b == 0) {
             rec(0).word = word;
             if (code == CH_DIV_L || code == CH_DIV_R) bc.mode = bc.mode < 1 ? 1 : bc.mode;
             if (code == CH_POW_L || code == CH_POW_R) bc.mode = 2;
-        } else if (rec(0).word != word) {
+        } else if (r >= P.n_ops || rec(0).word != word) {
             return false;
         }
         rec(b).word = word;
         rec(b).c = c;
     }
+    if (b == 0)
+        P.n_ops = (uint32_t)r;
+    else if (P.n_ops != r)
+        return false;
     const uint32_t n_in = (uint32_t)km + (samp ? 1u : 0u);
     if (b == 0)
         P.n_in = n_in;
@@ -335,7 +407,9 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
     for (int b = 0; b < batch; ++b) {
         kc_plane *p = planes[b];
         Chain *old = p->chain;
+        ChainLink *old_link = p->link;
         p->chain = nullptr;
+        p->link = nullptr;
         p->kind = kc_plane::MEM;
         p->dptr = outs[b]->dptr;
         p->pitch = outs[b]->pitch;
@@ -345,6 +419,7 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
         outs[b]->dptr = nullptr;
         plane_release(outs[b]);
         delete old;  // drops the operand references (after the launch is enqueued)
+        delete old_link;
     }
     return KC_OK;
 }
@@ -364,7 +439,10 @@ int planes_force(kc_plane *const *planes, int n)
     }
     if (todo.empty()) return KC_OK;  // constants / resident planes: nothing to launch
     KC_TRY(need_init());
-    for (auto *p : todo) KC_TRY(chain_prepare(p));
+    for (auto *p : todo) {
+        chain_flatten(p);
+        KC_TRY(chain_prepare(p));
+    }
     size_t i = 0;
     while (i < todo.size()) {
         BuiltChain bc;
@@ -437,17 +515,6 @@ static uint8_t code_for(int mix, bool acc_is_left)
     }
 }
 
-static int chain_distinct_inputs(const Chain &ch, const kc_plane *extra)
-{
-    std::vector<const kc_plane *> ins;
-    auto counts = [](const kc_plane *q) { return q->kind == kc_plane::MEM || q->kind == kc_plane::RESIZE; };
-    if (counts(ch.start)) input_index(ins, ch.start);
-    for (auto &s : ch.steps)
-        if (counts(s.operand)) input_index(ins, s.operand);
-    if (extra && counts(extra)) input_index(ins, extra);
-    return (int)ins.size();
-}
-
 int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
 {
     if (mix < KC_MIX_ADD || mix > KC_MIX_POW) {
@@ -469,7 +536,7 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
     bool acc_is_left = true;
     if (l->kind == kc_plane::LAZY && r->kind == kc_plane::LAZY) {
         // keep the longer chain lazy, run the shorter one now
-        if (l != r && l->chain->steps.size() >= r->chain->steps.size())
+        if (l != r && l->link->length >= r->link->length)
             KC_TRY(plane_force(r));
         else
             KC_TRY(plane_force(l));
@@ -483,36 +550,43 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
         opnd = l;
         acc_is_left = false;
     }
-    kc_plane *res = new kc_plane();
-    res->w = l->w;
-    res->h = l->h;
-    res->kind = kc_plane::LAZY;
-    res->chain = new Chain();
+    ChainLink *L = new ChainLink();
     if (acc) {
         // A chain that is full (steps or distinct inputs) is run first and restarted from its result.
-        if (acc->chain->steps.size() >= (size_t)KC_CHAIN_MAX_OPS ||
-            chain_distinct_inputs(*acc->chain, opnd) > KC_CHAIN_MAX_IN) {
+        L->n_in = acc->link->n_in;
+        for (int i = 0; i < L->n_in && i <= KC_CHAIN_MAX_IN; ++i) L->ins[i] = acc->link->ins[i];
+        link_add_input(*L, opnd);
+        if (acc->link->length >= (uint32_t)KC_CHAIN_MAX_OPS || L->n_in > KC_CHAIN_MAX_IN) {
             int s = plane_force(acc);
             if (s != KC_OK) {
-                plane_release(res);
+                delete L;
                 return s;
             }
             acc = nullptr;
         }
     }
     if (acc) {
-        res->chain->start = acc->chain->start;
-        plane_retain(res->chain->start);
-        res->chain->steps = acc->chain->steps;
-        for (auto &s : res->chain->steps) plane_retain(s.operand);
-        res->chain->steps.push_back({ code_for(mix, acc_is_left), opnd });
+        L->prev = acc;
+        plane_retain(acc);
+        L->step = { code_for(mix, acc_is_left), opnd };
         plane_retain(opnd);
+        L->length = acc->link->length + 1;
     } else {
-        res->chain->start = l;
+        L->prev = nullptr;
+        L->start = l;
         plane_retain(l);
-        res->chain->steps.push_back({ code_for(mix, true), r });
+        L->step = { code_for(mix, true), r };
         plane_retain(r);
+        L->length = 1;
+        L->n_in = 0;
+        link_add_input(*L, l);
+        link_add_input(*L, r);
     }
+    kc_plane *res = new kc_plane();
+    res->w = l->w;
+    res->h = l->h;
+    res->kind = kc_plane::LAZY;
+    res->link = L;
     *out = res;
     return KC_OK;
 }
