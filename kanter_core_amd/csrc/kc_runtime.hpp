@@ -4,6 +4,7 @@
 #include <deque>
 #include <set>
 #include <tuple>
+#include <unordered_map>
 
 #include "kc_internal.hpp"
 

@@ -195,6 +195,19 @@ static void link_add_input(ChainLink &L, const kc_plane *q)
     L.n_in++;  // may exceed the array: only the count matters beyond KC_CHAIN_MAX_IN
 }
 
+static int input_index(std::vector<const kc_plane *> &ins, const kc_plane *p);
+
+// Distinct planes a flat chain reads, as chain_fill will see them NOW.
+static int chain_distinct_inputs(const Chain &ch)
+{
+    std::vector<const kc_plane *> ins;
+    auto counts = [](const kc_plane *q) { return q->kind == kc_plane::MEM || q->kind == kc_plane::RESIZE; };
+    if (counts(ch.start)) input_index(ins, ch.start);
+    for (auto &s : ch.steps)
+        if (counts(s.operand)) input_index(ins, s.operand);
+    return (int)ins.size();
+}
+
 // Builds p->chain (start + steps in order) from the links; planes forced meanwhile end the walk.
 static void chain_flatten(kc_plane *p)
 {
@@ -273,6 +286,7 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
         return -1;
     };
     const int km = (int)ins.size();
+    if (km > KC_CHAIN_MAX_IN) return false;  // planes_force splits such chains before they get here
     float c0 = 0.0f;
     int start_src = slot(ch.start, &c0);
     if (start_src == -2) start_src = km;
@@ -441,6 +455,20 @@ int planes_force(kc_plane *const *planes, int n)
     KC_TRY(need_init());
     for (auto *p : todo) {
         chain_flatten(p);
+        // The input count was bounded when the chain was built, but a constant operand can have been
+        // materialised since (kc_plane_materialize, a resize of it ...) and now occupies an input slot.
+        // Then the prefix is run on its own and the chain restarts from its result.
+        while (chain_distinct_inputs(*p->chain) > KC_CHAIN_MAX_IN) {
+            kc_plane *prev = p->link->prev;
+            if (!prev || prev->kind != kc_plane::LAZY) {
+                set_error("chain with more than KC_CHAIN_MAX_IN inputs cannot be split");
+                return KC_ERR_UNSUPPORTED;
+            }
+            KC_TRY(plane_force(prev));
+            delete p->chain;
+            p->chain = nullptr;
+            chain_flatten(p);
+        }
         KC_TRY(chain_prepare(p));
     }
     size_t i = 0;
@@ -448,7 +476,10 @@ int planes_force(kc_plane *const *planes, int n)
         BuiltChain bc;
         kc_plane *group[KC_CHAIN_MAX_BATCH];
         int batch = 0;
-        chain_fill(bc, 0, todo[i]);
+        if (!chain_fill(bc, 0, todo[i])) {
+            set_error("internal: chain does not fit one program");
+            return KC_ERR_UNSUPPORTED;
+        }
         group[batch++] = todo[i];
         size_t j = i + 1;
         while (j < todo.size() && batch < KC_CHAIN_MAX_BATCH && todo[j]->w == todo[i]->w &&

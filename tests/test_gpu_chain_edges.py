@@ -243,3 +243,27 @@ def test_resize_operand_falls_back_when_the_program_is_not_eligible(kc, orc, n_s
     got = x.planes()
     assert kc.stats()["kernel_launches"] - l0 == 2
     assert_planes(got, [want], what="fallback %d %s" % (n_steps, op))
+
+
+def test_constant_operand_materialised_after_the_chain_was_built(kc, orc):
+    """A constant plane takes no input slot while it is a constant, but kc_plane_materialize (or a resize of
+    it) turns it into a resident plane IN PLACE.  A lazy chain that already reads four planes then reads five
+    when it is finally run: it must be split, not overflow the program's four input slots (found by UBSan under
+    the graph fuzzer)."""
+    h, w = 24, 40
+    planes = [splitmix_plane(SEED_A + i, 0, h, w) for i in range(5)]
+    imgs = [kc.SlotImage.from_planes([p]) for p in planes]
+    const = kc.SlotImage.from_value((w, h), 0.375, False)
+    x = kc.mix_process(imgs[0], imgs[1], kc.MixType.Add)
+    x = kc.mix_process(x, imgs[2], kc.MixType.Multiply)
+    x = kc.mix_process(x, const, kc.MixType.Subtract)
+    x = kc.mix_process(x, imgs[3], kc.MixType.Add)      # four resident inputs + one constant: one program
+    const.materialize()                                  # ... and now the constant is a fifth resident input
+    want = orc.mix_plane("Add", planes[0], planes[1])
+    want = orc.mix_plane("Multiply", want, planes[2])
+    want = orc.mix_plane("Subtract", want, np.full((h, w), 0.375, np.float32))
+    want = orc.mix_plane("Add", want, planes[3])
+    l0 = kc.stats()["kernel_launches"]
+    got = x.planes()[0]
+    assert kc.stats()["kernel_launches"] - l0 == 2, "prefix and remainder"
+    assert bit_equal(got, want)

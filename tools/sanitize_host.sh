@@ -2,6 +2,8 @@
 # Runs the CPU-side tests of the product library with its HOST code (runtime, graph, JSON, PNG, C API)
 # built under AddressSanitizer + UndefinedBehaviorSanitizer.  Device code is the regular build: GPU
 # sanitizers are not available on the target pool.  Restores the regular library afterwards.
+# On a GPU box the same host-only instrumentation can run the evaluator for real:
+#   KC_SANITIZE_TESTS=tests/test_gpu_fuzz_graphs.py tools/sanitize_host.sh -m gpu
 set -e
 cd "$(dirname "$0")/.."
 CL=/opt/rocm/lib/llvm/bin/clang++
@@ -20,4 +22,4 @@ cp $OUT/libkanter_core_amd.so kanter_core_amd/libkanter_core_amd.so
 trap 'cp $OUT/regular.so kanter_core_amd/libkanter_core_amd.so' EXIT
 RT=$($CL -print-file-name=libclang_rt.asan-x86_64.so)
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
-    python -m pytest tests/test_host_graph.py tests/test_cabi_symbols.py tests/test_multi_gpu_gloo.py -x -q "$@"
+    python -m pytest ${KC_SANITIZE_TESTS:-tests/test_host_graph.py tests/test_cabi_symbols.py tests/test_multi_gpu_gloo.py} -x -q "$@"
