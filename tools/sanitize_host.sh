@@ -7,19 +7,21 @@
 set -e
 cd "$(dirname "$0")/.."
 CL=/opt/rocm/lib/llvm/bin/clang++
+SAN=${KC_SANITIZER:-address,undefined}   # or: thread
 OUT=/tmp/kc_asan
 mkdir -p $OUT
 python -m kanter_core_amd.build >/dev/null
 for f in runtime ops resize graph json png c_api; do
-  $CL -x c++ -O1 -g -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer \
+  $CL -x c++ -O1 -g -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -fsanitize=$SAN -fno-omit-frame-pointer \
       -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Ikanter_core_amd/csrc -c kanter_core_amd/csrc/$f.cpp -o $OUT/$f.o &
 done
 wait
-$CL -shared -fPIC -fsanitize=address,undefined -shared-libsan -o $OUT/libkanter_core_amd.so kanter_core_amd/csrc/build/kernels.o \
+$CL -shared -fPIC -fsanitize=$SAN -shared-libsan -o $OUT/libkanter_core_amd.so kanter_core_amd/csrc/build/kernels.o \
     $OUT/{runtime,ops,resize,graph,json,png,c_api}.o -L/opt/rocm/lib -lamdhip64 -lz -Wl,-rpath,/opt/rocm/lib
 cp kanter_core_amd/libkanter_core_amd.so $OUT/regular.so
 cp $OUT/libkanter_core_amd.so kanter_core_amd/libkanter_core_amd.so
 trap 'cp $OUT/regular.so kanter_core_amd/libkanter_core_amd.so' EXIT
-RT=$($CL -print-file-name=libclang_rt.asan-x86_64.so)
+if [ "$SAN" = thread ]; then RT=$($CL -print-file-name=libclang_rt.tsan-x86_64.so); else RT=$($CL -print-file-name=libclang_rt.asan-x86_64.so); fi
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+    TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0 \
     python -m pytest ${KC_SANITIZE_TESTS:-tests/test_host_graph.py tests/test_cabi_symbols.py tests/test_multi_gpu_gloo.py} -x -q "$@"
