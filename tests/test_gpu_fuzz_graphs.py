@@ -58,8 +58,9 @@ def _policy(kc, rng, n_inputs):
     return [P.MostPixels, P.LeastPixels, P.LargestAxes, P.SmallestAxes][k]
 
 
-def _build(kc, orc, seed):
-    """-> (live graph, RefGraph, node ids to request)"""
+def _build(kc, orc, seed, info=None):
+    """-> (live graph, RefGraph, node ids to request); `info` (optional dict) receives what the mutation
+    fuzzer needs: embedded images, every output slot with its creator's position, every node with its slots."""
     rng = np.random.default_rng(seed)
     tp = kc.TextureProcessor.new()
     lg = tp.new_live_graph()
@@ -119,6 +120,12 @@ def _build(kc, orc, seed):
                 lg.connect(ins[slot][0], n, ins[slot][1], slot)
         outs.extend((n, s_, t) for s_, t in produces)
         made.append(n)
+        if info is not None:
+            slot_types = {"Mix": "XX", "SeparateRgba": "R", "CombineRgba": "GGGG", "HeightToNormal": "G"}
+            kind = kc.NodeType._KINDS[node.node_type.kind]
+            info.setdefault("nodes", []).append((n, kind, slot_types[kind], len(outs) - len(produces)))
+    if info is not None:
+        info["embedded"], info["outs"] = embedded, outs
     graph = json.loads(lg.node_graph().to_json())
     ref = orc.RefGraph(graph, embedded=embedded)
     k = min(len(made), int(rng.integers(1, 4)))
@@ -178,3 +185,61 @@ def test_random_graph_unfused_and_cached_agree(kc, orc, seed):
                 continue
             for pa, pb in zip(a, b):
                 assert_planes(pa, pb, what="seed %d" % seed)
+
+
+def _compare(kc, orc, lg, embedded, n, what):
+    ref = orc.RefGraph(json.loads(lg.node_graph().to_json()), embedded=embedded)
+    try:
+        want = ref.node_slot_datas(int(n))
+    except (RuntimeError, AssertionError):
+        with pytest.raises(kc.TexProError):
+            lg.await_clean(n)
+        return False
+    got = lg.await_clean(n).node_slot_datas(n)
+    assert len(got) == len(want), what
+    for g, w in zip(sorted(got, key=lambda s: s.slot_id), sorted(want, key=lambda s: s.slot_id)):
+        assert g.image.is_rgba() == w.image.is_rgba, what
+        assert_planes(g.image.planes(), w.image.planes, what=what)
+    return True
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_graph_edits_re_evaluate_like_a_fresh_graph(kc, orc, seed):
+    """The LiveGraph state machine: after every edit (another blend op, an input rewired to a different
+    producer, an edge removed, use_cache toggled, an intermediate result materialised behind the evaluator's
+    back) the requested node is recomputed and equals a fresh evaluation of the edited graph by the oracle."""
+    rng = np.random.default_rng(0xF0240000 + seed)
+    info = {}
+    lg, _, requested = _build(kc, orc, 0xF0240000 + seed, info)
+    if not requested:
+        return
+    target = requested[0]
+    if not _compare(kc, orc, lg, info["embedded"], target, "seed %d initial" % seed):
+        return
+    nodes, outs = info["nodes"], info["outs"]
+    for step in range(5):
+        n, kind, slots, first_out = nodes[rng.integers(len(nodes))]
+        edit = rng.integers(5)
+        if edit == 0 and kind == "Mix":
+            lg.set_mix_type(n, kc.MixType.parse(OPS[rng.integers(len(OPS))]))
+        elif edit == 1:
+            slot = int(rng.integers(len(slots)))
+            cands = [o for o in outs[:first_out] if slots[slot] == "X" or o[2] in (slots[slot], "X")]  # earlier producers only: no cycles
+            if cands:
+                src = cands[rng.integers(len(cands))]
+                lg.connect(src[0], n, src[1], slot)
+        elif edit == 2:
+            try:
+                lg.disconnect_slot(n, kc.Side.Input, int(rng.integers(len(slots))))
+            except kc.TexProError:  # SlotNotOccupied, as the reference reports it
+                pass
+        elif edit == 3:
+            lg.use_cache = not lg.use_cache
+        else:
+            try:
+                for sd in lg.node_slot_datas(n):  # whatever the node still holds: force it into HBM in place
+                    sd.image.materialize()
+            except kc.TexProError:
+                pass
+        if not _compare(kc, orc, lg, info["embedded"], target, "seed %d after edit %d (%d on node %d)" % (seed, step, edit, int(n))):
+            return
