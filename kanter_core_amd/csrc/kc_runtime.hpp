@@ -70,7 +70,15 @@ struct ChainLink {
     ChainStep step{};           // operand retained
     uint32_t length = 1;        // steps up to and including this one (an upper bound once a prev was forced)
     int n_in = 0;               // distinct MEM / RESIZE planes the whole chain reads (same bound)
-    const kc_plane *ins[KC_CHAIN_MAX_IN + 1] = {};
+    // Their identities BY VALUE (device pointer + pitch of a resident plane, address of a deferred resize):
+    // the planes themselves are kept alive by the links that use them, which may be gone once a prefix
+    // has been forced, so these are never dereferenced.  A stale entry only makes the bound more cautious.
+    struct InKey {
+        const void *p = nullptr;
+        size_t q = 0;
+        bool operator==(const InKey &o) const { return p == o.p && q == o.q; }
+    };
+    InKey ins[KC_CHAIN_MAX_IN + 1];
     ~ChainLink();
 };
 

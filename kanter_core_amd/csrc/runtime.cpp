@@ -180,18 +180,19 @@ ChainLink::~ChainLink()
     }
 }
 
-// Identity of a chain input, as input_index() sees it.
-static bool same_input(const kc_plane *a, const kc_plane *b)
-{
-    return a == b || (a->kind == kc_plane::MEM && b->kind == kc_plane::MEM && a->dptr == b->dptr && a->pitch == b->pitch);
-}
-
+// Identity of a chain input, as input_index() sees it, as a value (see ChainLink::InKey).
 static void link_add_input(ChainLink &L, const kc_plane *q)
 {
-    if (q->kind != kc_plane::MEM && q->kind != kc_plane::RESIZE) return;
-    for (int i = 0; i < L.n_in; ++i)
-        if (same_input(L.ins[i], q)) return;
-    if (L.n_in <= KC_CHAIN_MAX_IN) L.ins[L.n_in] = q;
+    ChainLink::InKey k;
+    if (q->kind == kc_plane::MEM)
+        k = { q->dptr, q->pitch };
+    else if (q->kind == kc_plane::RESIZE)
+        k = { q, ~(size_t)0 };
+    else
+        return;
+    for (int i = 0; i < L.n_in && i <= KC_CHAIN_MAX_IN; ++i)
+        if (L.ins[i] == k) return;
+    if (L.n_in <= KC_CHAIN_MAX_IN) L.ins[L.n_in] = k;
     L.n_in++;  // may exceed the array: only the count matters beyond KC_CHAIN_MAX_IN
 }
 
