@@ -13,7 +13,7 @@ import json
 import numpy as np
 import pytest
 
-from util import assert_planes
+from util import assert_planes, bit_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -243,3 +243,21 @@ def test_random_graph_edits_re_evaluate_like_a_fresh_graph(kc, orc, seed):
                 pass
         if not _compare(kc, orc, lg, info["embedded"], target, "seed %d after edit %d (%d on node %d)" % (seed, step, edit, int(n))):
             return
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_resizes_match_the_oracle(kc, orc, seed):
+    """Random source and target extents (1 .. ~700, log-uniform, independent per axis) and filters: tile edges,
+    partial 4-column groups, windows from 1 tap to hundreds, register-tap / LDS-table / two-pass forms."""
+    rng = np.random.default_rng(0xF0260000 + seed)
+    dim = lambda: int(np.exp(rng.uniform(0.0, np.log(700.0))))  # noqa: E731
+    sw, sh, dw, dh = max(1, dim()), max(1, dim()), max(1, dim()), max(1, dim())
+    filt = FILTERS[rng.integers(len(FILTERS))]
+    p = (rng.random((sh, sw), dtype=np.float32) * np.float32(1.5) - np.float32(0.25)).astype(np.float32)
+    if p.size >= 8:
+        p.reshape(-1)[rng.integers(p.size, size=4)] = [np.nan, np.inf, -np.inf, -0.0]
+    got = kc.resize_image(kc.SlotImage.from_planes([p]), (dw, dh), kc.ResizeFilter.parse(filt)).planes()[0]
+    want = orc.resize_plane(p, dw, dh, filt)
+    assert got.shape == want.shape
+    # bit for bit; NaN payloads are not part of the contract (inf * 0 is -qNaN on x86, +qNaN on the GPU)
+    assert bit_equal(got, want), "%s %dx%d -> %dx%d" % (filt, sw, sh, dw, dh)
