@@ -828,15 +828,16 @@ int kc_live_graph::process_one(uint32_t id)
     remove_nodes_data(id);
     for (auto &sd : outs) slot_datas.push_back(sd);
     if (!use_cache) {
-        // engine.rs:58-75
-        for (uint32_t parent : g.get_parents(id)) {
+        // engine.rs:58-75: a parent's planes are dropped once every child of it is Clean or Processing
+        // (edge lists straight from the index: a parent or child seen twice changes nothing)
+        for (auto &pe : edges) {
             bool all_done = true;
-            for (uint32_t child : g.get_children(parent)) {
+            for (auto &ce : g.edges_out_of(pe.output_id)) {
                 int st = KC_STATE_DIRTY;
-                (void)state_of(child, &st);
+                (void)state_of(ce.input_id, &st);
                 if (st != KC_STATE_CLEAN && st != KC_STATE_PROCESSING) all_done = false;
             }
-            if (all_done) remove_nodes_data(parent);
+            if (all_done) remove_nodes_data(pe.output_id);
         }
     }
     return set_state(id, KC_STATE_CLEAN);
