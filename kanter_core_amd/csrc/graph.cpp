@@ -76,6 +76,19 @@ std::vector<Slot> node_output_slots(const Node &n, bool *unimplemented)
     }
 }
 
+// node_output_slots(n).size() without building the named slot list (asked once per evaluated node)
+static size_t node_output_slot_count(const Node &n)
+{
+    switch (n.type) {
+    case KC_NODE_OUTPUT_GRAY: case KC_NODE_OUTPUT_RGBA: case KC_NODE_WRITE: return 0;
+    case KC_NODE_SEPARATE_RGBA: return 4;
+    case KC_NODE_GRAPH: return node_output_slots(n).size();
+    case KC_NODE_INPUT_GRAY: case KC_NODE_INPUT_RGBA: case KC_NODE_IMAGE: case KC_NODE_EMBED: case KC_NODE_VALUE:
+    case KC_NODE_MIX: case KC_NODE_HEIGHT_TO_NORMAL: case KC_NODE_COMBINE_RGBA: return 1;
+    default: return 0;
+    }
+}
+
 // SlotType::fits, src/node/mod.rs:209-221
 static bool slot_fits(int self, int other)
 {
@@ -628,7 +641,7 @@ int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData
         release_all(result);
         return s;
     }
-    if (!node.is_output() && result.size() != node_output_slots(node).size()) {
+    if (!node.is_output() && result.size() != node_output_slot_count(node)) {
         // node_type.rs:124-137
         set_error("the number of output buffers does not match the number of output slots");
         release_all(result);
