@@ -297,8 +297,8 @@ def main():
     launches_per_step = launches / args.steps
     achieved = alg_bytes / per_step_s / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_chain_kernel.json")
-    if os.path.exists(pmc) and args.workload == "chain32" and S == 4096 and N == 32:
+    pmc = os.path.join(ROOT, "profiles", "pmc_resize_chain_kernel.json" if args.workload == "resize_blend" else "pmc_chain_kernel.json")
+    if os.path.exists(pmc) and S == 4096 and ((args.workload == "chain32" and N == 32) or args.workload == "resize_blend"):
         try:
             with open(pmc) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")

@@ -13,6 +13,8 @@ import sys
 
 src = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_chain_kernel.json")
+alg = int(sys.argv[3]) if len(sys.argv) > 3 else 603979776  # algorithmic bytes per launch of the profiled workload
+what = sys.argv[4] if len(sys.argv) > 4 else "bench.py default (32-node chain, 4096x4096 f32x4), warm-up dispatches dropped"
 per = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> counter -> dispatch -> value
 for f in glob.glob(os.path.join(src, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -27,12 +29,12 @@ fetch = avg["FETCH_SIZE"] * 1024.0 * 2.0
 write = avg["WRITE_SIZE"] * 1024.0
 json.dump({
     "kernel": kernel.split("(")[0].replace("void ", ""),
-    "workload": "bench.py default (32-node chain, 4096x4096 f32x4), warm-up dispatches dropped",
+    "workload": what,
     "counters_avg_per_launch": {k: round(v, 1) for k, v in avg.items()},
     "fetch_bytes_corrected_x2": fetch,
     "write_bytes": write,
     "hbm_bytes_per_launch": fetch + write,
-    "algorithmic_bytes_per_launch": 603979776,
+    "algorithmic_bytes_per_launch": alg,
     "method": "rocprofv3 --kernel-trace --pmc <one counter group per pass> (profiles/run_pmc.sh); FETCH_SIZE doubled per "
               "MI355X_MICROARCH.md HBM section; WRITE_SIZE exact for 16-B stores; both in KiB",
 }, open(out, "w"), indent=1)
