@@ -267,9 +267,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(stepfn, steps, warmup, sync_ranks=True):
-        for _ in range(warmup):
+    def warm(stepfn, warmup):
+        # The first sightings of a chain program run through the interpreter while the program-specialised kernel
+        # compiles on a worker thread (csrc/specialize.cpp); the rest of the warm-up starts once it has landed.
+        early = min(warmup, 2)
+        for _ in range(early):
             stepfn()
+        kc.specialize_wait()
+        for _ in range(max(warmup - early, 1 if early else 0)):
+            stepfn()
+
+    def timed(stepfn, steps, warmup, sync_ranks=True):
+        warm(stepfn, warmup)
         launches0 = kc.stats()["kernel_launches"]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier() if sync_ranks else torch.cuda.synchronize()
@@ -283,7 +292,20 @@ def main():
         barrier() if sync_ranks else torch.cuda.synchronize()
         return t1 - t0, ev0.elapsed_time(ev1) * 1e-3, kc.stats()["kernel_launches"] - launches0
 
+    def step_spread(stepfn, steps):
+        """A second, separate pass with one HIP event after EVERY step (the events cost a few us of pipeline
+        overlap between consecutive launches, so they stay out of the timed region above): sorted step times in us."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        torch.cuda.synchronize()
+        evs[0].record(stream)
+        for i in range(steps):
+            stepfn()
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        return sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(steps))
+
     wall, dev_s, launches = timed(step, args.steps, args.warmup)
+    main_step_us = step_spread(step, max(20, min(args.steps, 100)))
     total_px = node_px
     if world > 1:
         t = torch.tensor([wall, node_px], device=red_dev, dtype=torch.float64)
@@ -331,6 +353,10 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_step, 1.0) if launches_per_step else alg_bytes,
             "kernel_us": round(per_step_s / max(launches_per_step, 1.0) * 1e6, 2),
             "launches_per_step": launches_per_step,
+            # separate pass, one HIP event after every step (>= 20 steps): spread of individual steps, event overhead included
+            "step_us_median": round(main_step_us[len(main_step_us) // 2], 2), "step_us_min": round(main_step_us[0], 2),
+            "step_us_max": round(main_step_us[-1], 2),
+            "specialized_kernel": bool(kc.specialize_stats()["specialized_launches"]),
         },
     }
 

@@ -129,6 +129,24 @@ KC_API int kc_get_fusion(void);
 /* Pool statistics: bytes currently handed out, bytes cached for reuse, kernels launched. */
 KC_API int kc_stats(uint64_t *bytes_in_use, uint64_t *bytes_cached, uint64_t *kernel_launches);
 KC_API int kc_pool_trim(void);
+/* Run-time specialisation of the fused Mix-chain kernel.  A chain of N Mix nodes (src/node/mix.rs:136-192
+ * applied N times) normally runs through a step-table interpreter; a program that keeps coming back is also
+ * emitted as straight-line HIP, compiled with hiprtc (same parity flags as the offline build) and used from
+ * then on.  Results are bit-identical either way; this is a throughput knob only.
+ *   mode 0: interpreter only.  mode 1 (default, env KC_SPECIALIZE): compile in the background once a program
+ *   has been seen `after` times (default 2; <= 0 keeps the current value); launches never wait.
+ *   mode 2: compile at the first sighting, the launch waits for the compiler (tests, batch jobs).
+ * kc_specialize_wait blocks until every queued compile has landed. */
+KC_API int kc_set_specialize(int mode, int after);
+KC_API int kc_get_specialize(void);
+KC_API int kc_specialize_wait(void);
+KC_API int kc_specialize_stats(uint64_t *kernels_compiled, uint64_t *compiles_failed, uint64_t *specialized_launches,
+                               uint64_t *compiles_pending);
+/* Diagnostics: generates the specialised kernel for a program given as step words (ChainCode | (source + 1) << 8,
+ * source = -1 for the step's constant, k for input plane k) and compiles it for gfx950 WITHOUT loading it -- works
+ * without a device.  The generated source is copied to `source` (NUL-terminated, truncated to `cap`) when given. */
+KC_API int kc_specialize_compile_check(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, int flat,
+                                       char *source, size_t cap);
 
 /* ========================================================================================== *
  * Planes -- replaces Buffer / TransientBufferContainer (src/slot_image.rs:12,

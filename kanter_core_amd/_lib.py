@@ -43,6 +43,11 @@ SIGNATURES = {
     "kc_set_fusion": (C.c_int, [C.c_int]),
     "kc_get_fusion": (C.c_int, []),
     "kc_stats": (C.c_int, [C.POINTER(C.c_uint64)] * 3),
+    "kc_set_specialize": (C.c_int, [C.c_int, C.c_int]),
+    "kc_get_specialize": (C.c_int, []),
+    "kc_specialize_wait": (C.c_int, []),
+    "kc_specialize_stats": (C.c_int, [C.POINTER(C.c_uint64)] * 4),
+    "kc_specialize_compile_check": (C.c_int, [c_u32p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "kc_pool_trim": (C.c_int, []),
     "kc_plane_alloc": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(c_vp)]),
     "kc_plane_const": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(c_vp)]),

@@ -87,6 +87,36 @@ def set_fusion(enabled):
     _check(_lib.load().kc_set_fusion(int(bool(enabled))))
 
 
+def set_specialize(mode, after=0):
+    """Run-time specialisation of the fused chain kernel: 0 interpreter only, 1 compile in the background once a
+    program has been seen `after` times (default), 2 compile at first sight and wait.  Bit-identical results."""
+    _check(_lib.load().kc_set_specialize(int(mode), int(after)))
+
+
+def get_specialize():
+    return _lib.load().kc_get_specialize()
+
+
+def specialize_wait():
+    """Blocks until every queued kernel compile has landed."""
+    _check(_lib.load().kc_specialize_wait())
+
+
+def specialize_stats():
+    v = [C.c_uint64() for _ in range(4)]
+    _check(_lib.load().kc_specialize_stats(*[C.byref(x) for x in v]))
+    return dict(zip(("kernels_compiled", "compiles_failed", "specialized_launches", "compiles_pending"), [x.value for x in v]))
+
+
+def specialize_compile_check(words, n_in, start_src=0, flat=True):
+    """Generates and compiles (without loading; no device needed) the specialised kernel of a step program.
+    Returns the generated source."""
+    arr = (C.c_uint32 * len(words))(*words)
+    buf = C.create_string_buffer(1 << 16)
+    _check(_lib.load().kc_specialize_compile_check(arr, len(words), int(n_in), int(start_src), int(bool(flat)), buf, len(buf)))
+    return buf.value.decode()
+
+
 def stats():
     a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
     _check(_lib.load().kc_stats(C.byref(a), C.byref(b), C.byref(c)))

@@ -23,11 +23,30 @@ using namespace kc;
 
 typedef std::lock_guard<std::recursive_mutex> Lock;
 
+// No C++ exception may cross the C ABI (callers are C, Rust, ctypes): every entry point that can
+// allocate is a function-try-block ending in KC_CATCH.
+#define KC_CATCH                                                        \
+    catch (const std::bad_alloc &)                                      \
+    {                                                                   \
+        set_error("host allocation failed");                            \
+        return KC_ERR_OUT_OF_MEMORY;                                    \
+    }                                                                   \
+    catch (const std::exception &kc_exc_)                                   \
+    {                                                                   \
+        set_error(std::string("internal error: ") + kc_exc_.what());        \
+        return KC_ERR_GENERIC;                                          \
+    }                                                                   \
+    catch (...)                                                         \
+    {                                                                   \
+        set_error("internal error");                                    \
+        return KC_ERR_GENERIC;                                          \
+    }
+
 extern "C" {
 
 // ---------------------------------------------------------------- context
 int kc_init(int device_ordinal)
-{
+try {
     Context &c = ctx();
     Lock lk(c.mu);
     if (c.inited) {
@@ -64,16 +83,22 @@ int kc_init(int device_ordinal)
         int v = std::atoi(cu);
         if (v == 1 || v == 2 || v == 4 || v == 6 || v == 8) c.chain_unroll = v;
     }
+    if (const char *sp = std::getenv("KC_SPECIALIZE")) {
+        int v = std::atoi(sp);
+        if (v >= 0 && v <= 2) specialize_set_mode(v, 0);
+    }
     c.inited = true;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_shutdown(void)
-{
+try {
     Context &c = ctx();
     Lock lk(c.mu);
     if (!c.inited) return KC_OK;
     (void)hipStreamSynchronize(c.stream);
+    specialize_shutdown();
     pool_trim();
     for (auto &kv : c.taps) (void)hipFree(kv.second.dev_block);
     c.taps.clear();
@@ -83,11 +108,12 @@ int kc_shutdown(void)
     c.device = -1;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_is_initialized(void) { return ctx().inited ? 1 : 0; }
 
 int kc_set_stream(void *hip_stream)
-{
+try {
     KC_TRY(need_init());
     Context &c = ctx();
     Lock lk(c.mu);
@@ -99,15 +125,17 @@ int kc_set_stream(void *hip_stream)
     }
     return KC_OK;
 }
+KC_CATCH
 
 void *kc_get_stream(void) { return (void *)ctx().stream; }
 
 int kc_sync(void)
-{
+try {
     KC_TRY(need_init());
     KC_HIP(hipStreamSynchronize(ctx().stream));
     return KC_OK;
 }
+KC_CATCH
 
 const char *kc_last_error(void) { return last_error().c_str(); }
 
@@ -144,15 +172,67 @@ const char *kc_status_string(int s)
 }
 
 int kc_set_fusion(int enabled)
-{
+try {
     ctx().fusion = enabled != 0;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_get_fusion(void) { return ctx().fusion ? 1 : 0; }
 
+int kc_set_specialize(int mode, int after)
+try {
+    KC_ARG(mode >= 0 && mode <= 2);
+    return specialize_set_mode(mode, after);
+}
+KC_CATCH
+
+int kc_get_specialize(void) { return specialize_get_mode(); }
+
+int kc_specialize_wait(void)
+try {
+    specialize_wait();
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_specialize_stats(uint64_t *compiled, uint64_t *failed, uint64_t *launches, uint64_t *pending)
+try {
+    specialize_stats(compiled, failed, launches, pending);
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_specialize_compile_check(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, int flat, char *source,
+                                size_t cap)
+try {
+    KC_ARG(words && n_ops >= 1 && n_ops <= (uint32_t)KC_CHAIN_MAX_OPS && n_in <= (uint32_t)KC_CHAIN_MAX_IN);
+    KC_ARG(start_src >= -1 && start_src < (int)n_in);
+    ChainProgram P;
+    std::memset(&P, 0, sizeof P);
+    P.n_ops = n_ops;
+    P.n_in = n_in;
+    P.start_src = start_src;
+    P.rows = flat ? 1u : 2u;
+    P.row_units = 1;
+    for (uint32_t i = 0; i < n_ops; ++i) {
+        const uint32_t from = words[i] >> 8;
+        KC_ARG((words[i] & 0xffu) <= CH_MUL_INV && from <= n_in);
+        ((i & 1u) ? P.step[0][i / 2].b : P.step[0][i / 2].a).word = words[i];
+    }
+    if (source && cap) {
+        const std::string src = specialize_source(P);
+        std::snprintf(source, cap, "%s", src.c_str());
+    }
+    std::string log;
+    int s = specialize_compile_only(P, &log);
+    if (s != KC_OK) set_error("specialised chain kernel did not compile: " + log);
+    return s;
+}
+KC_CATCH
+
 int kc_stats(uint64_t *in_use, uint64_t *cached, uint64_t *launches)
-{
+try {
     Context &c = ctx();
     Lock lk(c.mu);
     if (in_use) *in_use = c.bytes_in_use;
@@ -160,29 +240,33 @@ int kc_stats(uint64_t *in_use, uint64_t *cached, uint64_t *launches)
     if (launches) *launches = c.launches;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_pool_trim(void)
-{
+try {
     KC_TRY(need_init());
     return pool_trim();
 }
+KC_CATCH
 
 // ---------------------------------------------------------------- planes
 int kc_plane_alloc(uint32_t w, uint32_t h, kc_plane **out)
-{
+try {
     KC_ARG(out);
     return plane_new_mem(w, h, out);
 }
+KC_CATCH
 
 int kc_plane_const(uint32_t w, uint32_t h, float v, kc_plane **out)
-{
+try {
     KC_ARG(out && w > 0 && h > 0);
     *out = plane_new_const(w, h, v);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_plane_wrap(void *dptr, uint32_t w, uint32_t h, size_t pitch, kc_plane **out)
-{
+try {
     KC_TRY(need_init());
     KC_ARG(out && dptr && w > 0 && h > 0);
     // kernels move 16 bytes per lane: rows must start 16-byte aligned and be readable in whole
@@ -201,55 +285,62 @@ int kc_plane_wrap(void *dptr, uint32_t w, uint32_t h, size_t pitch, kc_plane **o
     *out = p;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_plane_retain(kc_plane *p)
-{
+try {
     KC_ARG(p);
     plane_retain(p);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_plane_release(kc_plane *p)
-{
+try {
     if (!p) return KC_OK;
     Lock lk(ctx().mu);
     plane_release(p);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_plane_size(const kc_plane *p, uint32_t *w, uint32_t *h)
-{
+try {
     KC_ARG(p);
     if (w) *w = p->w;
     if (h) *h = p->h;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_plane_is_const(const kc_plane *p, int *is_const, float *v)
-{
+try {
     KC_ARG(p);
     if (is_const) *is_const = p->kind == kc_plane::CONST;
     if (v) *v = p->cval;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_plane_materialize(kc_plane *p)
-{
+try {
     KC_ARG(p);
     return plane_materialize(p);
 }
+KC_CATCH
 
 int kc_plane_device_ptr(kc_plane *p, void **dptr, size_t *pitch)
-{
+try {
     KC_ARG(p);
     KC_TRY(plane_materialize(p));
     if (dptr) *dptr = p->dptr;
     if (pitch) *pitch = p->pitch;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_plane_upload_f32(kc_plane *p, const float *host, size_t host_pitch)
-{
+try {
     KC_TRY(need_init());
     KC_ARG(p && host && p->kind == kc_plane::MEM);
     if (host_pitch == 0) host_pitch = (size_t)p->w * 4;
@@ -258,9 +349,10 @@ int kc_plane_upload_f32(kc_plane *p, const float *host, size_t host_pitch)
     KC_HIP(hipStreamSynchronize(ctx().stream));
     return KC_OK;
 }
+KC_CATCH
 
 int kc_plane_download_f32(kc_plane *p, float *host, size_t host_pitch)
-{
+try {
     KC_ARG(p && host);
     if (host_pitch == 0) host_pitch = (size_t)p->w * 4;
     Lock lk(ctx().mu);
@@ -277,95 +369,108 @@ int kc_plane_download_f32(kc_plane *p, float *host, size_t host_pitch)
     KC_HIP(hipStreamSynchronize(ctx().stream));
     return KC_OK;
 }
+KC_CATCH
 
 // ---------------------------------------------------------------- images
 int kc_image_gray(kc_plane *p, kc_image **out)
-{
+try {
     KC_ARG(p && out);
     *out = image_new(1, &p);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_rgba(kc_plane *const planes[4], kc_image **out)
-{
+try {
     KC_ARG(planes && out && planes[0] && planes[1] && planes[2] && planes[3]);
     for (int i = 1; i < 4; ++i) KC_ARG(planes[i]->w == planes[0]->w && planes[i]->h == planes[0]->h);
     *out = image_new(4, planes);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_retain(kc_image *img)
-{
+try {
     KC_ARG(img);
     image_retain(img);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_release(kc_image *img)
-{
+try {
     if (!img) return KC_OK;
     Lock lk(ctx().mu);
     image_release(img);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_is_rgba(const kc_image *img, int *is_rgba)
-{
+try {
     KC_ARG(img && is_rgba);
     *is_rgba = img->is_rgba();
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_size(const kc_image *img, kc_size *size)
-{
+try {
     KC_ARG(img && size);
     *size = kc_size{ img->w(), img->h() };
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_plane(const kc_image *img, int channel, kc_plane **out)
-{
+try {
     KC_ARG(img && out && channel >= 0 && channel < img->n);
     *out = img->planes[channel];
     plane_retain(*out);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_from_value(kc_size size, float v, int rgba, kc_image **out)
-{
+try {
     KC_ARG(out);
     return image_from_value(size, v, rgba != 0, out);
 }
+KC_CATCH
 
 int kc_image_as_type(const kc_image *img, int rgba, kc_image **out)
-{
+try {
     KC_ARG(img && out);
     return image_as_type(const_cast<kc_image *>(img), rgba != 0, out);
 }
+KC_CATCH
 
 int kc_image_materialize(kc_image *img)
-{
+try {
     KC_ARG(img);
     Lock lk(ctx().mu);
     KC_TRY(image_force(img));
     for (int i = 0; i < img->n; ++i) KC_TRY(plane_materialize(img->planes[i]));
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_image **out)
-{
+try {
     KC_ARG(out);
     return image_from_u8(host, w, h, channels, out);  // synchronises: host buffer may be reused on return
 }
+KC_CATCH
 
 int kc_image_to_u8(kc_image *img, int srgb, uint8_t *host)
-{
+try {
     KC_ARG(img && host);
     return image_to_u8(img, srgb != 0, host);
 }
+KC_CATCH
 
 int kc_image_from_f32(const float *const host_planes[], int n, uint32_t w, uint32_t h, kc_image **out)
-{
+try {
     KC_ARG(host_planes && out && (n == 1 || n == 4));
     kc_plane *p[4] = { nullptr, nullptr, nullptr, nullptr };
     int s = KC_OK;
@@ -377,18 +482,20 @@ int kc_image_from_f32(const float *const host_planes[], int n, uint32_t w, uint3
     for (int i = 0; i < n; ++i) plane_release(p[i]);
     return s;
 }
+KC_CATCH
 
 int kc_image_to_f32(kc_image *img, float *const host_planes[], int n)
-{
+try {
     KC_ARG(img && host_planes && n == img->n);
     Lock lk(ctx().mu);
     KC_TRY(image_force(img));  // one batched launch for R, G, B
     for (int i = 0; i < n; ++i) KC_TRY(kc_plane_download_f32(img->planes[i], host_planes[i], 0));
     return KC_OK;
 }
+KC_CATCH
 
 int kc_image_read_png(const char *path, kc_image **out)
-{
+try {
     KC_ARG(path && out);
     std::vector<uint8_t> px;
     uint32_t w = 0, h = 0;
@@ -396,31 +503,35 @@ int kc_image_read_png(const char *path, kc_image **out)
     KC_TRY(png_read(path, px, w, h, ch));
     return kc_image_from_u8(px.data(), w, h, ch, out);
 }
+KC_CATCH
 
 int kc_image_write_png(kc_image *img, const char *path)
-{
+try {
     KC_ARG(img && path);
     std::vector<uint8_t> px((size_t)img->w() * img->h() * 4);
     KC_TRY(image_to_u8(img, false, px.data()));
     return png_write_rgba8(path, px.data(), img->w(), img->h());
 }
+KC_CATCH
 
 // ---------------------------------------------------------------- operators
 int kc_calculate_size(int policy, const kc_size *sizes, int n, int slot_index, kc_size specific, kc_size *out)
-{
+try {
     KC_ARG(out && (n == 0 || sizes));
     return calculate_size(policy, sizes, n, slot_index, specific, out);
 }
+KC_CATCH
 
 int kc_resize_image(kc_image *src, kc_size size, int filter, kc_image **out)
-{
+try {
     KC_ARG(src && out);
     return resize_image(src, size, filter, out);
 }
+KC_CATCH
 
 int kc_resize_buffers(kc_image *const images[], const kc_edge keys[], int n, const kc_edge *edges_sorted, int n_edges,
                       int policy, uint32_t policy_slot, kc_size policy_size, int filter, kc_image *out[])
-{
+try {
     KC_ARG(n >= 0 && (n == 0 || (images && keys && out)));
     if (n == 0) return KC_OK;  // shared.rs:147-149
     std::vector<kc_size> sizes;
@@ -457,60 +568,69 @@ int kc_resize_buffers(kc_image *const images[], const kc_edge keys[], int n, con
     }
     return KC_OK;
 }
+KC_CATCH
 
 int kc_mix_process(kc_image *left, kc_image *right, int mix_type, kc_image **out)
-{
+try {
     KC_ARG(out);
     return mix_process(left, right, mix_type, out);
 }
+KC_CATCH
 
 int kc_separate_rgba_process(kc_image *input, kc_image *out[4])
-{
+try {
     KC_ARG(out);
     return separate_process(input, out);
 }
+KC_CATCH
 
 int kc_combine_rgba_process(kc_image *const inputs[4], kc_image **out)
-{
+try {
     KC_ARG(inputs && out);
     return combine_process(inputs, out);
 }
+KC_CATCH
 
 int kc_value_process(float v, kc_image **out)
-{
+try {
     KC_ARG(out);
     return value_process(v, out);
 }
+KC_CATCH
 
 int kc_height_to_normal_process(kc_image *input, kc_image **out)
-{
+try {
     KC_ARG(out);
     return height_to_normal_process(input, out);
 }
+KC_CATCH
 
 // ---------------------------------------------------------------- NodeGraph
 int kc_node_graph_new(kc_node_graph **out)
-{
+try {
     KC_ARG(out);
     *out = new kc_node_graph();
     return KC_OK;
 }
+KC_CATCH
 
 int kc_node_graph_clone(const kc_node_graph *g, kc_node_graph **out)
-{
+try {
     KC_ARG(g && out);
     *out = new kc_node_graph(*g);
     return KC_OK;
 }
+KC_CATCH
 
 int kc_node_graph_free(kc_node_graph *g)
-{
+try {
     delete g;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_node_graph_from_json(const char *json, kc_node_graph **out)
-{
+try {
     KC_ARG(json && out);
     kc_node_graph *g = new kc_node_graph();
     int s = graph_from_json(json, g->g);
@@ -521,9 +641,10 @@ int kc_node_graph_from_json(const char *json, kc_node_graph **out)
     *out = g;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_node_graph_from_path(const char *path, kc_node_graph **out)
-{
+try {
     KC_ARG(path && out);
     std::ifstream f(path);
     if (!f) {
@@ -534,9 +655,10 @@ int kc_node_graph_from_path(const char *path, kc_node_graph **out)
     ss << f.rdbuf();
     return kc_node_graph_from_json(ss.str().c_str(), out);
 }
+KC_CATCH
 
 int kc_node_graph_to_json(const kc_node_graph *g, char *buf, size_t cap, size_t *needed)
-{
+try {
     KC_ARG(g);
     std::string s = graph_to_json(g->g);
     if (needed) *needed = s.size() + 1;
@@ -547,9 +669,10 @@ int kc_node_graph_to_json(const kc_node_graph *g, char *buf, size_t cap, size_t 
     }
     return KC_OK;
 }
+KC_CATCH
 
 int kc_node_graph_export_json(const kc_node_graph *g, const char *path)
-{
+try {
     KC_ARG(g && path);
     std::ofstream f(path);
     if (!f) {
@@ -559,55 +682,64 @@ int kc_node_graph_export_json(const kc_node_graph *g, const char *path)
     f << graph_to_json(g->g);
     return f.good() ? KC_OK : KC_ERR_IO;
 }
+KC_CATCH
 
 int kc_node_graph_add_node(kc_node_graph *g, const kc_node_desc *node, uint32_t *id)
-{
+try {
     KC_ARG(g && node);
     return g->g.add_node(node_from_desc(*node), id);
 }
+KC_CATCH
 
 int kc_node_graph_add_node_with_id(kc_node_graph *g, const kc_node_desc *node)
-{
+try {
     KC_ARG(g && node);
     return g->g.add_node_with_id(node_from_desc(*node));
 }
+KC_CATCH
 
 int kc_node_graph_connect(kc_node_graph *g, uint32_t on, uint32_t in, uint32_t os, uint32_t is)
-{
+try {
     KC_ARG(g);
     return g->g.connect(on, in, os, is);
 }
+KC_CATCH
 
 int kc_node_graph_try_connect(kc_node_graph *g, uint32_t on, uint32_t in, uint32_t os, uint32_t is)
-{
+try {
     KC_ARG(g);
     return g->g.try_connect(on, in, os, is);
 }
+KC_CATCH
 
 int kc_node_graph_remove_node(kc_node_graph *g, uint32_t id)
-{
+try {
     KC_ARG(g);
     return g->g.remove_node(id, nullptr);
 }
+KC_CATCH
 
 int kc_node_graph_remove_edge(kc_node_graph *g, kc_edge e)
-{
+try {
     KC_ARG(g);
     return g->g.remove_edge(e);
 }
+KC_CATCH
 
 int kc_node_graph_disconnect_slot(kc_node_graph *g, uint32_t id, int side, uint32_t slot)
-{
+try {
     KC_ARG(g);
     return g->g.disconnect_slot(id, side, slot, nullptr);
 }
+KC_CATCH
 
 int kc_node_graph_node_count(const kc_node_graph *g, uint32_t *count)
-{
+try {
     KC_ARG(g && count);
     *count = (uint32_t)g->g.nodes.size();
     return KC_OK;
 }
+KC_CATCH
 
 static int copy_ids(const std::vector<uint32_t> &v, uint32_t *ids, uint32_t cap, uint32_t *count)
 {
@@ -626,21 +758,23 @@ static int copy_edges(const std::vector<kc_edge> &v, kc_edge *edges, uint32_t ca
 }
 
 int kc_node_graph_node_ids(const kc_node_graph *g, uint32_t *ids, uint32_t cap, uint32_t *count)
-{
+try {
     KC_ARG(g);
     std::vector<uint32_t> v;
     for (auto &n : g->g.nodes) v.push_back(n.node_id);
     return copy_ids(v, ids, cap, count);
 }
+KC_CATCH
 
 int kc_node_graph_edges(const kc_node_graph *g, kc_edge *edges, uint32_t cap, uint32_t *count)
-{
+try {
     KC_ARG(g);
     return copy_edges(g->g.edges, edges, cap, count);
 }
+KC_CATCH
 
 int kc_node_graph_input_slot_id_with_name(const kc_node_graph *g, const char *name, uint32_t *slot)
-{
+try {
     KC_ARG(g && name && slot);
     for (auto &n : g->g.nodes)
         if (n.is_input() && n.text == name) {
@@ -649,9 +783,10 @@ int kc_node_graph_input_slot_id_with_name(const kc_node_graph *g, const char *na
         }
     return KC_ERR_INVALID_NAME;
 }
+KC_CATCH
 
 int kc_node_graph_output_slot_id_with_name(const kc_node_graph *g, const char *name, uint32_t *slot)
-{
+try {
     KC_ARG(g && name && slot);
     for (auto &n : g->g.nodes)
         if (n.is_output() && n.text == name) {
@@ -660,15 +795,17 @@ int kc_node_graph_output_slot_id_with_name(const kc_node_graph *g, const char *n
         }
     return KC_ERR_INVALID_NAME;
 }
+KC_CATCH
 
 int kc_node_graph_set_mix_type(kc_node_graph *g, uint32_t id, int mix)
-{
+try {
     KC_ARG(g && mix >= KC_MIX_ADD && mix <= KC_MIX_POW);
     Node *n = g->g.find(id);
     if (!n || n->type != KC_NODE_MIX) return KC_ERR_INVALID_NODE_ID;
     n->mix_type = mix;
     return KC_OK;
 }
+KC_CATCH
 
 static int copy_name(const std::string &s, char *buf, size_t cap)
 {
@@ -681,75 +818,83 @@ static int copy_name(const std::string &s, char *buf, size_t cap)
 }
 
 int kc_node_graph_set_image_node_path(kc_node_graph *g, uint32_t id, const char *path)
-{
+try {
     KC_ARG(g && path);
     Node *n = g->g.find(id);
     if (!n || n->type != KC_NODE_IMAGE) return KC_ERR_INVALID_NODE_ID;
     n->text = path;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_node_graph_rename_output_node(kc_node_graph *g, uint32_t id, const char *new_name, char *old_name, size_t cap)
-{
+try {
     KC_ARG(g && new_name);
     std::string old;
     KC_TRY(g->g.rename_output_node(id, new_name, &old));
     return copy_name(old, old_name, cap);
 }
+KC_CATCH
 
 // ---------------------------------------------------------------- TextureProcessor / LiveGraph
 int kc_tex_pro_new(uint64_t memory_threshold, kc_tex_pro **out)
-{
+try {
     KC_ARG(out);
     kc_tex_pro *tp = new kc_tex_pro();
     tp->memory_threshold = memory_threshold;
     *out = tp;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_tex_pro_free(kc_tex_pro *tp)
-{
+try {
     delete tp;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_tex_pro_new_live_graph(kc_tex_pro *tp, kc_live_graph **out)
-{
+try {
     KC_ARG(tp && out);
     kc_live_graph *lg = new kc_live_graph();
     lg->tp = tp;
     *out = lg;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_free(kc_live_graph *lg)
-{
+try {
     if (!lg) return KC_OK;
     Lock lk(ctx().mu);
     delete lg;
     return KC_OK;
 }
+KC_CATCH
 
 #define LG_LOCK(lg) KC_ARG(lg); Lock _ctx_lock(ctx().mu)
 
 int kc_live_graph_set_flags(kc_live_graph *lg, int auto_update, int use_cache)
-{
+try {
     LG_LOCK(lg);
     lg->auto_update = auto_update != 0;
     lg->use_cache = use_cache != 0;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_get_flags(const kc_live_graph *lg, int *auto_update, int *use_cache)
-{
+try {
     KC_ARG(lg);
     if (auto_update) *auto_update = lg->auto_update;
     if (use_cache) *use_cache = lg->use_cache;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_set_node_graph(kc_live_graph *lg, const kc_node_graph *g)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(g);
     lg->g = g->g;
@@ -757,56 +902,64 @@ int kc_live_graph_set_node_graph(kc_live_graph *lg, const kc_node_graph *g)
     lg->clear_data();
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_node_graph(const kc_live_graph *lg, kc_node_graph **out)
-{
+try {
     KC_ARG(lg && out);
     kc_node_graph *g = new kc_node_graph();
     g->g = lg->g;
     *out = g;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_add_node(kc_live_graph *lg, const kc_node_desc *node, uint32_t *id)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(node);
     return lg->add_node(node_from_desc(*node), id);
 }
+KC_CATCH
 
 int kc_live_graph_add_node_with_id(kc_live_graph *lg, const kc_node_desc *node)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(node);
     return lg->add_node_with_id(node_from_desc(*node));
 }
+KC_CATCH
 
 int kc_live_graph_remove_node(kc_live_graph *lg, uint32_t id)
-{
+try {
     LG_LOCK(lg);
     return lg->remove_node(id);
 }
+KC_CATCH
 
 int kc_live_graph_connect(kc_live_graph *lg, uint32_t on, uint32_t in, uint32_t os, uint32_t is)
-{
+try {
     LG_LOCK(lg);
     return lg->connect(on, in, os, is);
 }
+KC_CATCH
 
 int kc_live_graph_remove_edge(kc_live_graph *lg, kc_edge e)
-{
+try {
     LG_LOCK(lg);
     return lg->remove_edge(e);
 }
+KC_CATCH
 
 int kc_live_graph_disconnect_slot(kc_live_graph *lg, uint32_t id, int side, uint32_t slot)
-{
+try {
     LG_LOCK(lg);
     return lg->disconnect_slot(id, side, slot);
 }
+KC_CATCH
 
 int kc_live_graph_set_mix_type(kc_live_graph *lg, uint32_t id, int mix)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(mix >= KC_MIX_ADD && mix <= KC_MIX_POW);
     Node *n = lg->g.find(id);
@@ -816,18 +969,20 @@ int kc_live_graph_set_mix_type(kc_live_graph *lg, uint32_t id, int mix)
     n->mix_type = mix;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_rename_output_node(kc_live_graph *lg, uint32_t id, const char *new_name, char *old_name, size_t cap)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(new_name);
     std::string old;
     KC_TRY(lg->g.rename_output_node(id, new_name, &old));
     return copy_name(old, old_name, cap);
 }
+KC_CATCH
 
 int kc_live_graph_set_resize(kc_live_graph *lg, uint32_t id, int policy, uint32_t slot, kc_size size, int filter)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(policy >= 0 && policy <= KC_POLICY_SPECIFIC_SIZE && filter >= 0 && filter <= KC_FILTER_LANCZOS3);
     Node *n = lg->g.find(id);
@@ -839,45 +994,51 @@ int kc_live_graph_set_resize(kc_live_graph *lg, uint32_t id, int policy, uint32_
     n->filter = filter;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_node_state(const kc_live_graph *lg, uint32_t id, int *state)
-{
+try {
     KC_ARG(lg && state);
     return lg->state_of(id, state);
 }
+KC_CATCH
 
 int kc_live_graph_request(kc_live_graph *lg, uint32_t id)
-{
+try {
     LG_LOCK(lg);
     int st;
     KC_TRY(lg->state_of(id, &st));
     if (st == KC_STATE_DIRTY) lg->node_state[id] = KC_STATE_REQUESTED;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_prioritise(kc_live_graph *lg, uint32_t id)
-{
+try {
     LG_LOCK(lg);
     int st;
     KC_TRY(lg->state_of(id, &st));
     if (st == KC_STATE_DIRTY || st == KC_STATE_REQUESTED) lg->node_state[id] = KC_STATE_PRIORITISED;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_await_clean(kc_live_graph *lg, uint32_t id)
-{
+try {
     LG_LOCK(lg);
     return lg->await_clean(id);
 }
+KC_CATCH
 
 int kc_live_graph_update(kc_live_graph *lg)
-{
+try {
     LG_LOCK(lg);
     return lg->update();
 }
+KC_CATCH
 
 int kc_live_graph_slot_data(kc_live_graph *lg, uint32_t node, uint32_t slot, kc_image **out)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(out);
     const SlotData *sd = lg->find_slot(node, slot);
@@ -886,9 +1047,10 @@ int kc_live_graph_slot_data(kc_live_graph *lg, uint32_t node, uint32_t slot, kc_
     *out = sd->image;
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_slot_data_size(kc_live_graph *lg, uint32_t node, uint32_t slot, kc_size *size)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(size);
     const SlotData *sd = lg->find_slot(node, slot);
@@ -896,36 +1058,40 @@ int kc_live_graph_slot_data_size(kc_live_graph *lg, uint32_t node, uint32_t slot
     *size = kc_size{ sd->image->w(), sd->image->h() };
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_slot_in_memory(kc_live_graph *lg, uint32_t node, uint32_t slot, int *in_memory)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(in_memory);
     if (!lg->find_slot(node, slot)) return KC_ERR_NO_SLOT_DATA;
     *in_memory = 1;  // planes never leave HBM: there is no disk tier to page out to
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_node_slot_ids(kc_live_graph *lg, uint32_t node, uint32_t *slots, uint32_t cap, uint32_t *count)
-{
+try {
     LG_LOCK(lg);
     std::vector<uint32_t> v;
     for (auto &sd : lg->slot_datas)
         if (sd.node_id == node) v.push_back(sd.slot_id);
     return copy_ids(v, slots, cap, count);
 }
+KC_CATCH
 
 int kc_live_graph_buffer_rgba(kc_live_graph *lg, uint32_t node, uint32_t slot, int srgb, uint8_t *host)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(host);
     const SlotData *sd = lg->find_slot(node, slot);
     if (!sd) return KC_ERR_NO_SLOT_DATA;
     return image_to_u8(sd->image, srgb != 0, host);
 }
+KC_CATCH
 
 int kc_live_graph_embed_slot_data_with_id(kc_live_graph *lg, kc_image *image, uint32_t slot_id, uint32_t embed_id)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(image);
     for (auto &e : lg->embedded)
@@ -934,49 +1100,56 @@ int kc_live_graph_embed_slot_data_with_id(kc_live_graph *lg, kc_image *image, ui
     lg->embedded.push_back(EmbeddedSlotData{ embed_id, slot_id, image });
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_add_input_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image *image)
-{
+try {
     LG_LOCK(lg);
     KC_ARG(image);
     image_retain(image);
     lg->input_slot_datas.push_back(SlotData{ node_id, slot_id, image });
     return KC_OK;
 }
+KC_CATCH
 
 int kc_live_graph_changed_consume(kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count)
-{
+try {
     LG_LOCK(lg);
     std::vector<uint32_t> v(lg->changed.begin(), lg->changed.end());
     if (ids && cap >= v.size()) lg->changed.clear();  // a NULL / short buffer only queries the count
     return copy_ids(v, ids, cap, count);
 }
+KC_CATCH
 
 int kc_live_graph_output_ids(const kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count)
-{
+try {
     KC_ARG(lg);
     return copy_ids(lg->g.output_ids(), ids, cap, count);
 }
+KC_CATCH
 
 int kc_live_graph_node_ids(const kc_live_graph *lg, uint32_t *ids, uint32_t cap, uint32_t *count)
-{
+try {
     KC_ARG(lg);
     std::vector<uint32_t> v;
     for (auto &n : lg->g.nodes) v.push_back(n.node_id);
     return copy_ids(v, ids, cap, count);
 }
+KC_CATCH
 
 int kc_live_graph_edges(const kc_live_graph *lg, kc_edge *edges, uint32_t cap, uint32_t *count)
-{
+try {
     KC_ARG(lg);
     return copy_edges(lg->g.edges, edges, cap, count);
 }
+KC_CATCH
 
 int kc_live_graph_set_base_dir(kc_live_graph *lg, const char *dir)
-{
+try {
     LG_LOCK(lg);
     lg->base_dir = dir ? dir : "";
     return KC_OK;
 }
+KC_CATCH
 
 }  // extern "C"

@@ -346,11 +346,16 @@ std::vector<uint32_t> NodeGraph::get_children(uint32_t id) const
 
 std::vector<uint32_t> NodeGraph::get_children_recursive(uint32_t id) const
 {
-    std::vector<uint32_t> out = get_children(id);
-    std::vector<uint32_t> direct = out;
-    for (uint32_t c : direct) {
-        auto sub = get_children_recursive(c);
-        out.insert(out.end(), sub.begin(), sub.end());
+    // node_graph.rs:566-575 recurses child by child (and never returns on a cycle, which connect() does not
+    // forbid); every caller only needs the set of descendants, so this is a worklist with a visited set.
+    std::vector<uint32_t> out, work = get_children(id);
+    std::set<uint32_t> seen(work.begin(), work.end());
+    while (!work.empty()) {
+        const uint32_t c = work.back();
+        work.pop_back();
+        out.push_back(c);
+        for (uint32_t g : get_children(c))
+            if (seen.insert(g).second) work.push_back(g);
     }
     return out;
 }
@@ -698,14 +703,27 @@ int kc_live_graph::state_of(uint32_t id, int *st) const
 
 int kc_live_graph::set_state(uint32_t id, int st)
 {
-    // :515-537
+    // :515-537.  Dirty propagates to the children; a node that already is Dirty ends the walk.  The reference
+    // recurses before it stores the node's own state, which never terminates on a cyclic graph: here the
+    // state is stored first and the children go on a worklist (same final states on every acyclic graph).
     int old;
     KC_TRY(state_of(id, &old));
-    if (st != old) {
-        if (st == KC_STATE_DIRTY)
-            for (uint32_t c : g.get_children(id)) KC_TRY(set_state(c, st));
-        node_state[id] = (st == KC_STATE_DIRTY && old == KC_STATE_PROCESSING) ? KC_STATE_PROCESSING_DIRTY : st;
+    if (st == old) return KC_OK;
+    if (st != KC_STATE_DIRTY) {
+        node_state[id] = st;
         changed.insert(id);
+        return KC_OK;
+    }
+    std::vector<uint32_t> work{ id };
+    while (!work.empty()) {
+        const uint32_t n = work.back();
+        work.pop_back();
+        int cur;
+        KC_TRY(state_of(n, &cur));
+        if (cur == KC_STATE_DIRTY) continue;
+        node_state[n] = cur == KC_STATE_PROCESSING ? KC_STATE_PROCESSING_DIRTY : KC_STATE_DIRTY;
+        changed.insert(n);
+        for (uint32_t c : g.get_children(n)) work.push_back(c);
     }
     return KC_OK;
 }
@@ -856,18 +874,50 @@ int kc_live_graph::process_one(uint32_t id)
     return set_state(id, KC_STATE_CLEAN);
 }
 
-int kc_live_graph::ensure_clean(uint32_t id, int guard)
+int kc_live_graph::ensure_clean(uint32_t root)
 {
-    if (guard > 100000) {
-        set_error("graph has a cycle");
-        return KC_ERR_NODE_PROCESSING;
-    }
-    int st;
-    KC_TRY(state_of(id, &st));
-    if (st == KC_STATE_CLEAN) return KC_OK;
-    // parents first (LiveGraph::get_closest_processable, :279-311, collapsed into a DFS)
-    const std::vector<kc_edge> edges = g.edges_into(id);
-    for (auto &e : edges) {
+    // Parents first (LiveGraph::get_closest_processable, :279-311, collapsed into a depth-first walk).  The
+    // walk keeps its own stack -- a 100 000-node chain must not exhaust the thread's -- and the set of nodes
+    // on it: an edge back into that set is a cycle, which connect() and the JSON reader accept (as the
+    // reference's do) and which can never become Clean.
+    struct Frame {
+        uint32_t id;
+        std::vector<kc_edge> edges;  // a copy: processing may touch the graph
+        size_t next = 0;
+        bool awaiting = false;  // edges[next - 1]'s producer has just been brought up to date
+    };
+    std::deque<Frame> stack;
+    std::set<uint32_t> on_stack;
+    auto enter = [&](uint32_t id) -> int {
+        int st;
+        KC_TRY(state_of(id, &st));
+        if (st == KC_STATE_CLEAN) return KC_OK;
+        if (!on_stack.insert(id).second) {
+            set_error("graph has a cycle through node " + std::to_string(id));
+            return KC_ERR_NODE_PROCESSING;
+        }
+        stack.push_back(Frame{ id, g.edges_into(id) });
+        return KC_OK;
+    };
+    KC_TRY(enter(root));
+    while (!stack.empty()) {
+        Frame &f = stack.back();
+        if (f.awaiting) {
+            const kc_edge &e = f.edges[f.next - 1];
+            f.awaiting = false;
+            if (!find_slot(e.output_id, e.output_slot)) {
+                set_error("a parent produced no data for a connected slot");
+                return KC_ERR_NO_SLOT_DATA;
+            }
+        }
+        if (f.next == f.edges.size()) {
+            const uint32_t id = f.id;
+            stack.pop_back();
+            on_stack.erase(id);
+            KC_TRY(process_one(id));
+            continue;
+        }
+        const kc_edge e = f.edges[f.next++];
         int pst;
         if (state_of(e.output_id, &pst) != KC_OK) continue;  // parent deleted
         if (pst == KC_STATE_CLEAN && !find_slot(e.output_id, e.output_slot)) {
@@ -879,13 +929,10 @@ int kc_live_graph::ensure_clean(uint32_t id, int guard)
             if (!has_slot) return KC_ERR_NO_SLOT_DATA;
             KC_TRY(set_state(e.output_id, KC_STATE_DIRTY));
         }
-        KC_TRY(ensure_clean(e.output_id, guard + 1));
-        if (!find_slot(e.output_id, e.output_slot)) {
-            set_error("a parent produced no data for a connected slot");
-            return KC_ERR_NO_SLOT_DATA;
-        }
+        f.awaiting = true;
+        KC_TRY(enter(e.output_id));  // may invalidate f
     }
-    return process_one(id);
+    return KC_OK;
 }
 
 int kc_live_graph::await_clean(uint32_t id)
@@ -893,7 +940,7 @@ int kc_live_graph::await_clean(uint32_t id)
     if (!g.find(id)) return KC_ERR_INVALID_NODE_ID;
     ResizeMemoScope memo;
     if (auto_update) KC_TRY(update());
-    KC_TRY(ensure_clean(id, 0));
+    KC_TRY(ensure_clean(id));
     // Clean means computed: whatever the node still holds is brought into HBM now.
     for (auto &sd : slot_datas)
         if (sd.node_id == id) KC_TRY(image_force(sd.image));
@@ -915,7 +962,7 @@ int kc_live_graph::update()
     }
     for (uint32_t id : requested) {
         if (!g.find(id)) continue;
-        KC_TRY(ensure_clean(id, 0));
+        KC_TRY(ensure_clean(id));
     }
     for (uint32_t id : requested)
         for (auto &sd : slot_datas)

@@ -16,63 +16,7 @@
 
 namespace kc {
 
-// ------------------------------------------------------------------------------------------
-// Fused pointwise chain: acc = start; for each step acc = op(acc, x) or op(x, acc).
-// One program drives up to KC_CHAIN_MAX_BATCH planes (the R, G, B planes of an RGBA Mix share
-// ops but not operands), blockIdx.y selects the plane.
-// ------------------------------------------------------------------------------------------
-constexpr int KC_CHAIN_MAX_OPS = 64;
-constexpr int KC_CHAIN_MAX_IN = 4;
-constexpr int KC_CHAIN_MAX_BATCH = 4;
-
-// Step codes: which side the running value sits on matters for -, / and pow.
-enum ChainCode : uint8_t {
-    CH_ADD = 0,    // acc + x
-    CH_SUB_L = 1,  // acc - x
-    CH_SUB_R = 2,  // x - acc
-    CH_MUL = 3,    // acc * x
-    CH_DIV_L = 4,  // acc / x
-    CH_DIV_R = 5,  // x / acc
-    CH_POW_L = 6,  // acc ^ x
-    CH_POW_R = 7,  // x ^ acc
-    CH_ADD_R = 8,  // x + acc: host-side only, canonicalised to CH_ADD before launch (same IEEE sum)
-    CH_MUL_R = 9,  // x * acc: host-side only, canonicalised to CH_MUL
-    // Device-side only (chain_fill): a {+, -, *} step on a plane operand x followed by an invert-style
-    // step "c - acc" (Mix(Subtract)(constant, .), how every graph spells 1 - x) is ONE record and one
-    // dispatch.  Both roundings happen, in order: the result is that of the two separate steps.
-    CH_ADD_INV = 10,   // c - (acc + x)
-    CH_SUBL_INV = 11,  // c - (acc - x)
-    CH_SUBR_INV = 12,  // c - (x - acc)
-    CH_MUL_INV = 13    // c - (acc * x)
-};
-
-// word: bits 0-7 ChainCode, bits 8-15 operand source (0 = the constant c, k + 1 = input plane k).
-struct ChainStepRec {
-    uint32_t word;
-    float c;
-};
-struct alignas(16) ChainStepPair {  // steps 2i and 2i + 1: one 16-byte scalar load
-    ChainStepRec a, b;
-};
-
-struct ChainProgram {
-    uint32_t n_ops;
-    uint32_t n_in;
-    uint32_t row_units;  // vector units (float4 or float) per row; rows * row_units = work items
-    uint32_t rows;
-    int32_t start_src;  // input index, or -1: start from start_c
-    const float *in[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];
-    uint32_t in_pitch[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];  // in vector units
-    float *out[KC_CHAIN_MAX_BATCH];
-    uint32_t out_pitch[KC_CHAIN_MAX_BATCH];
-    float start_c[KC_CHAIN_MAX_BATCH];
-    // resize_chain_kernel only: the source plane of the resampled operand (input slot n_in - 1)
-    const float *samp_src[KC_CHAIN_MAX_BATCH];
-    uint32_t samp_pitch[KC_CHAIN_MAX_BATCH];  // in floats
-    // One 8-byte record per step and channel, fetched two at a time by one scalar (SMEM) load; one
-    // spare pair lets the loop prefetch the next pair unconditionally.
-    ChainStepPair step[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_OPS / 2 + 1];
-};
+#include "chain_program.h"  // ChainCode, ChainStepRec / ChainStepPair, ChainProgram
 
 // Per-axis tap table of the separable resampler, resident in HBM.
 struct TapsDev {

@@ -154,6 +154,8 @@ int planes_force(kc_plane *const *planes, int n);       // batches chains that s
 int plane_materialize(kc_plane *p);                     // LAZY/CONST -> MEM
 // l op r for one channel (src/node/mix.rs:136-192): lazy chain, constant fold or immediate kernel.
 int plane_mix(int mix_type, kc_plane *l, kc_plane *r, kc_plane **out);
+// Batches the forces plane_mix would do one plane at a time (the channels of one Mix node).
+int planes_mix_prepare(kc_plane *const *ls, kc_plane *const *rs, int n);
 Operand plane_operand(const kc_plane *p);               // MEM or CONST only
 
 kc_image *image_new(int n, kc_plane *const *planes);    // retains the planes
@@ -182,6 +184,17 @@ int resize_force_many(kc_plane *const *planes, int n);  // same; equal resamples
 // (phase 2 feeds the chain program).  *launched = false when the case is not eligible (taps not
 // in registers, tile does not fit LDS, program too long): the caller forces the RESIZE planes.
 int chain_resize_launch(const ChainProgram &P, int batch, int mode, kc_plane *const *sampled, bool *launched);
+
+// ---- run-time specialisation of the chain kernel (specialize.cpp) ----
+hipError_t launch_chain_specialized(const ChainProgram &P, int batch, hipStream_t s, bool *launched);
+int specialize_set_mode(int mode, int after);  // 0 off, 1 background compile after `after` sightings, 2 compile at once
+int specialize_get_mode();
+void specialize_wait();
+void specialize_stats(uint64_t *compiled, uint64_t *failed, uint64_t *launches, uint64_t *pending);
+std::string specialize_last_log();
+void specialize_shutdown();
+std::string specialize_source(const ChainProgram &P);
+int specialize_compile_only(const ChainProgram &P, std::string *log);
 
 // ---- png / json (png.cpp, json.cpp) ----
 int png_read(const std::string &path, std::vector<uint8_t> &px, uint32_t &w, uint32_t &h, int &channels);
@@ -317,7 +330,7 @@ struct kc_live_graph {
     int connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is);
     int remove_edge(kc_edge e);
     int disconnect_slot(uint32_t id, int side, uint32_t slot);
-    int ensure_clean(uint32_t id, int depth_guard);
+    int ensure_clean(uint32_t id);
     int await_clean(uint32_t id);
     int update();
     int process_one(uint32_t id);

@@ -207,6 +207,7 @@ int mix_process(kc_image *left_in, kc_image *right_in, int mix_type, kc_image **
     } else if (left->is_rgba()) {
         // R, G, B mixed; A := 1.0; input alphas are never read (mix.rs:199-213)
         kc_plane *p[4] = { nullptr, nullptr, nullptr, nullptr };
+        s = planes_mix_prepare(left->planes, right->planes, 3);
         for (int c = 0; c < 3 && s == KC_OK; ++c) s = plane_mix(mix_type, left->planes[c], right->planes[c], &p[c]);
         if (s == KC_OK) {
             p[3] = plane_new_const(left->w(), left->h(), 1.0f);

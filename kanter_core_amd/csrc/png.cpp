@@ -82,6 +82,12 @@ int png_read(const std::string &path, std::vector<uint8_t> &px, uint32_t &w, uin
     }
     const size_t stride = ((size_t)w * chans * depth + 7) / 8;
     const size_t bpp = std::max<size_t>(1, (size_t)chans * depth / 8);
+    // deflate expands at most 1032:1: a header that promises more than the IDAT bytes can hold is corrupt
+    // (and must not drive the allocations below -- a 100-byte file could otherwise ask for 17 GB)
+    if ((stride + 1) * h > idat.size() * 1032 + 64) {
+        set_error(path + ": corrupt PNG stream (image larger than its data)");
+        return KC_ERR_IMAGE;
+    }
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf raw_len = raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), idat.size()) != Z_OK || raw_len != raw.size()) {

@@ -412,7 +412,10 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
         P.row_units = row_units;
     }
     if (!launched) {
-        hipError_t e = launch_chain(P, batch, bc.mode, c.max_blocks, c.chain_unroll, c.stream);
+        // a program-specialised straight-line kernel if one has been compiled (specialize.cpp) ...
+        hipError_t e = launch_chain_specialized(P, batch, c.stream, &launched);
+        // ... otherwise the interpreter
+        if (e == hipSuccess && !launched) e = launch_chain(P, batch, bc.mode, c.max_blocks, c.chain_unroll, c.stream);
         if (e != hipSuccess) {
             for (auto *o : outs) plane_release(o);
             return hip_fail(e, "launch_chain");
@@ -531,8 +534,7 @@ static float fold_const(int mix, float l, float r)
     case KC_MIX_ADD: return l + r;
     case KC_MIX_SUBTRACT: return l - r;
     case KC_MIX_MULTIPLY: return l * r;
-    case KC_MIX_DIVIDE: return l / r;
-    default: return (float)std::pow((double)l, (double)r);  // same f64-then-round rule as the kernel
+    default: return l / r;  // KC_MIX_DIVIDE (Pow is never folded on the host, see plane_mix)
     }
 }
 
@@ -547,6 +549,40 @@ static uint8_t code_for(int mix, bool acc_is_left)
     }
 }
 
+// Would continuing `acc` with a step on `opnd` exceed one program (steps or distinct input planes)?
+static bool chain_full_with(const kc_plane *acc, const kc_plane *opnd)
+{
+    ChainLink probe;
+    probe.n_in = acc->link->n_in;
+    for (int i = 0; i < probe.n_in && i <= KC_CHAIN_MAX_IN; ++i) probe.ins[i] = acc->link->ins[i];
+    link_add_input(probe, opnd);
+    return acc->link->length >= (uint32_t)KC_CHAIN_MAX_OPS || probe.n_in > KC_CHAIN_MAX_IN;
+}
+
+// Which of two lazy operands plane_mix runs first: the shorter chain (the right one on a tie).
+static kc_plane *lazy_pair_victim(kc_plane *l, kc_plane *r)
+{
+    return (l != r && l->link->length >= r->link->length) ? r : l;
+}
+
+// The planes plane_mix(l[c], r[c]) would have to run before it can extend a chain, forced TOGETHER: the R, G
+// and B chains of an RGBA operand share one program and leave as one launch (blockIdx.y) instead of three.
+int planes_mix_prepare(kc_plane *const *ls, kc_plane *const *rs, int n)
+{
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    std::vector<kc_plane *> todo;
+    for (int c = 0; c < n; ++c)
+        if (ls[c]->kind == kc_plane::LAZY && rs[c]->kind == kc_plane::LAZY) todo.push_back(lazy_pair_victim(ls[c], rs[c]));
+    if (!todo.empty()) KC_TRY(planes_force(todo.data(), (int)todo.size()));
+    todo.clear();
+    for (int c = 0; c < n; ++c) {
+        kc_plane *acc = ls[c]->kind == kc_plane::LAZY ? ls[c] : rs[c]->kind == kc_plane::LAZY ? rs[c] : nullptr;
+        if (acc && chain_full_with(acc, acc == ls[c] ? rs[c] : ls[c])) todo.push_back(acc);
+    }
+    if (!todo.empty()) KC_TRY(planes_force(todo.data(), (int)todo.size()));
+    return KC_OK;
+}
+
 int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
 {
     if (mix < KC_MIX_ADD || mix > KC_MIX_POW) {
@@ -558,7 +594,10 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
         return KC_ERR_INVALID_ARG;
     }
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-    if (l->kind == kc_plane::CONST && r->kind == kc_plane::CONST) {
+    // Constants fold on the host -- except Pow: powf is evaluated by the device's own routine (pow_positive,
+    // <= 1 ulp from libm), and a folded constant must be the value a pixel of the same operands would get,
+    // so constant ^ constant stays a (zero-input) chain and is computed by the kernel.
+    if (l->kind == kc_plane::CONST && r->kind == kc_plane::CONST && mix != KC_MIX_POW) {
         *out = plane_new_const(l->w, l->h, fold_const(mix, l->cval, r->cval));
         return KC_OK;
     }
@@ -566,13 +605,7 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
     // Pick the running value: a lazy operand is continued, the other side becomes the step operand.
     kc_plane *acc = nullptr, *opnd = nullptr;
     bool acc_is_left = true;
-    if (l->kind == kc_plane::LAZY && r->kind == kc_plane::LAZY) {
-        // keep the longer chain lazy, run the shorter one now
-        if (l != r && l->link->length >= r->link->length)
-            KC_TRY(plane_force(r));
-        else
-            KC_TRY(plane_force(l));
-    }
+    if (l->kind == kc_plane::LAZY && r->kind == kc_plane::LAZY) KC_TRY(plane_force(lazy_pair_victim(l, r)));  // keep the longer chain lazy
     if (l->kind == kc_plane::LAZY) {
         acc = l;
         opnd = r;
@@ -582,20 +615,16 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
         opnd = l;
         acc_is_left = false;
     }
+    // A chain that is full (steps or distinct inputs) is run first and restarted from its result.
+    if (acc && chain_full_with(acc, opnd)) {
+        KC_TRY(plane_force(acc));
+        acc = nullptr;
+    }
     ChainLink *L = new ChainLink();
     if (acc) {
-        // A chain that is full (steps or distinct inputs) is run first and restarted from its result.
         L->n_in = acc->link->n_in;
         for (int i = 0; i < L->n_in && i <= KC_CHAIN_MAX_IN; ++i) L->ins[i] = acc->link->ins[i];
         link_add_input(*L, opnd);
-        if (acc->link->length >= (uint32_t)KC_CHAIN_MAX_OPS || L->n_in > KC_CHAIN_MAX_IN) {
-            int s = plane_force(acc);
-            if (s != KC_OK) {
-                delete L;
-                return s;
-            }
-            acc = nullptr;
-        }
     }
     if (acc) {
         L->prev = acc;

@@ -241,3 +241,61 @@ def test_try_buffer_rgba_requests_when_not_clean(live_graph):
     assert e.value.kind == "InvalidNodeId" and live_graph.node_state(out) == NodeState.Requested
     live_graph.update()
     assert live_graph.node_state(out) == NodeState.Clean
+
+
+def _mix():
+    return Node.new(NodeType.Mix(MixType.Add))
+
+
+def test_cyclic_graph_is_an_error_not_a_crash(live_graph):
+    # connect() accepts a cycle exactly as the reference's does (node_graph.rs:416-446 has no check); the
+    # reference then recurses without bound in set_state / get_children_recursive.  Here every walk
+    # terminates and asking for a node on the cycle reports it.
+    lg = live_graph
+    a, b, c = lg.add_node(_mix()), lg.add_node(_mix()), lg.add_node(_mix())
+    lg.connect(a, b, SlotId(0), SlotId(0))
+    lg.connect(b, c, SlotId(0), SlotId(0))
+    lg.connect(c, a, SlotId(0), SlotId(0))
+    for n in (a, b, c):
+        assert lg.node_state(n) == NodeState.Dirty
+    with pytest.raises(TexProError) as e:
+        lg.await_clean(b)
+    assert "cycle" in str(e.value)
+    # the mutators that walk descendants terminate too
+    lg.disconnect_slot(b, Side.Input, SlotId(0))
+    lg.connect(a, b, SlotId(0), SlotId(0))
+    lg.remove_node(c)
+    assert lg.node_state(a) == NodeState.Dirty
+
+
+def test_self_loop_is_reported(live_graph):
+    lg = live_graph
+    a = lg.add_node(_mix())
+    lg.connect(a, a, SlotId(0), SlotId(1))
+    with pytest.raises(TexProError):
+        lg.await_clean(a)
+
+
+def test_cycle_in_json_graph_is_reported(live_graph):
+    g = NodeGraph.new()
+    a, b = g.add_node(_mix()), g.add_node(_mix())
+    g.connect(a, b, SlotId(0), SlotId(0))
+    g.connect(b, a, SlotId(0), SlotId(0))
+    again = NodeGraph.from_json(g.to_json())
+    lg = live_graph
+    lg.set_node_graph(again)
+    with pytest.raises(TexProError):
+        lg.await_clean(b)
+
+
+def test_dirty_propagation_walks_a_very_long_chain_without_recursion(live_graph):
+    lg = live_graph
+    n = 2000
+    ids = [lg.add_node(_mix())]
+    for _ in range(n):
+        nxt = lg.add_node(_mix())
+        lg.connect(ids[-1], nxt, SlotId(0), SlotId(0))
+        ids.append(nxt)
+    lg.changed_consume()
+    lg.connect(ids[0], ids[1], SlotId(0), SlotId(1))
+    assert lg.node_state(ids[-1]) == NodeState.Dirty

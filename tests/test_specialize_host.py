@@ -1,0 +1,63 @@
+"""Run-time specialiser of the fused chain kernel, host side (no GPU): every step code generates source that
+compiles for gfx950 with the parity flags (hiprtc cross-compiles without a device), and the generated text is
+the straight-line form of the program -- one statement per record, constants read from the argument block."""
+import pytest
+
+import kanter_core_amd as kc
+
+ADD, SUB_L, SUB_R, MUL, DIV_L, DIV_R, POW_L, POW_R = range(8)
+ADD_INV, SUBL_INV, SUBR_INV, MUL_INV = 10, 11, 12, 13
+
+
+def word(code, src):
+    return code | ((src + 1) << 8)
+
+
+def test_baseline_program_is_sixteen_straight_line_statements():
+    # the 32-node BASELINE graph: 16 records "1 - (acc op B)", op alternating +, *
+    words = [word(ADD_INV if i % 2 == 0 else MUL_INV, 1) for i in range(16)]
+    src = kc.specialize_compile_check(words, n_in=2, start_src=0, flat=True)
+    body = src[src.index('extern "C"'):]
+    assert body.count("acc = ") == 17  # start + 16 records
+    assert "pp[0].a.c - (acc + in1)" in body and "pp[0].b.c - (acc * in1)" in body and "pp[7].b.c - (acc * in1)" in body
+    assert "switch" not in body and "for (" not in body
+    assert "__launch_bounds__(64)" in body
+    assert "pow_positive" not in src  # only programs with a pow step carry the routine
+
+
+@pytest.mark.parametrize("flat", [True, False])
+def test_every_step_code_compiles(flat):
+    plane_codes = [ADD, SUB_L, SUB_R, MUL, DIV_L, DIV_R, POW_L, POW_R, ADD_INV, SUBL_INV, SUBR_INV, MUL_INV]
+    const_codes = [ADD, SUB_L, SUB_R, MUL, DIV_L, DIV_R, POW_L, POW_R]
+    words = [word(c, i % 4) for i, c in enumerate(plane_codes)] + [word(c, -1) for c in const_codes]
+    src = kc.specialize_compile_check(words, n_in=4, start_src=3, flat=flat)
+    assert "pow4(acc, in2)" in src and "pow_positive" in src
+    assert ("idx / P.row_units" in src) == (not flat)
+
+
+def test_constant_start_and_zero_inputs():
+    src = kc.specialize_compile_check([word(MUL, -1), word(SUB_R, -1)], n_in=0, start_src=-1)
+    assert "P.start_c[b]" in src
+
+
+def test_invalid_programs_are_refused():
+    with pytest.raises(kc.TexProError):
+        kc.specialize_compile_check([word(ADD, 2)], n_in=2)      # operand slot out of range
+    with pytest.raises(kc.TexProError):
+        kc.specialize_compile_check([word(14, 0)], n_in=1)       # unknown code
+    with pytest.raises(kc.TexProError):
+        kc.specialize_compile_check([word(ADD, 0)], n_in=1, start_src=1)
+
+
+def test_mode_knob_round_trips():
+    old = kc.get_specialize()
+    try:
+        for m in (0, 2, 1):
+            kc.set_specialize(m)
+            assert kc.get_specialize() == m
+        with pytest.raises(kc.TexProError):
+            kc.set_specialize(3)
+    finally:
+        kc.set_specialize(old)
+    kc.specialize_wait()
+    assert kc.specialize_stats()["compiles_pending"] == 0
