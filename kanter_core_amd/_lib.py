@@ -185,4 +185,8 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        # The kernel specialiser's compile thread is stopped while the interpreter is still whole (the library
+        # also stops it from a C exit handler; this one runs first and keeps pending compiles from delaying exit).
+        import atexit
+        atexit.register(lambda: lib.kc_set_specialize(0, 0))
     return _lib

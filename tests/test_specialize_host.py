@@ -21,7 +21,7 @@ def test_baseline_program_is_sixteen_straight_line_statements():
     assert body.count("acc = ") == 17  # start + 16 records
     assert "pp[0].a.c - (acc + in1)" in body and "pp[0].b.c - (acc * in1)" in body and "pp[7].b.c - (acc * in1)" in body
     assert "switch" not in body and "for (" not in body
-    assert "__launch_bounds__(64)" in body
+    assert "__launch_bounds__(256)" in body
     assert "pow_positive" not in src  # only programs with a pow step carry the routine
 
 
