@@ -66,7 +66,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="chain32", choices=["chain32", "chain32_rows", "mix1", "resize_blend", "fanin"])
+    ap.add_argument("--workload", default=None, choices=["chain32", "chain32_rows", "mix1", "resize_blend", "fanin"],
+                    help="default: chain32 (the headline) on one GPU, fanin (BASELINE config #4, partitioned by the library) on several")
+    ap.add_argument("--policy", default="spread", choices=["spread", "auto"], help="fanin: placement policy of the partitioner")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,6 +76,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N > 1 control flow on one GPU")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "chain32" if args.gpus == 1 else "fanin"
 
     import numpy as np
     import torch
@@ -194,78 +198,67 @@ def main():
         kernel = "resize_chain_kernel<2,3>"
         desc = "B %d^2 -> %d^2 Triangle resize + 3-node blend chain, BASELINE config #2" % (s_small, S)
     else:  # fanin
+        # BASELINE config #4 as ONE graph that every rank builds: 8 independent 16-node subgraphs + a fixed-order 7-node
+        # Mix(Add) tree.  The library's partitioner (csrc/partition.cpp) places the subgraphs on the ranks and the join
+        # region on the home rank; multi_gpu.PartitionedEvaluator moves the cut slots (RCCL send / recv over xGMI, R, G, B
+        # of each branch result; the constant alpha travels as a scalar).  Each rank embeds only the sources placed on it.
+        from kanter_core_amd.multi_gpu import PartitionedEvaluator
         n_branches, sub_nodes = 8, 16
-        mine = multi_gpu.assign_branches(n_branches, world)[rank]
-        most = max(len(x) for x in multi_gpu.assign_branches(n_branches, world))
-        branches = []
-        for bidx in mine:
-            ha = [splitmix_plane(0x5EED0100 + bidx, c, S, S) for c in range(4)]
-            hb = [splitmix_plane(0x5EED0200 + bidx, c, S, S) for c in range(4)]
-            lg = tp.new_live_graph()
-            na, nb = embed(kc, lg, kc.SlotImage.from_planes(ha), 0), embed(kc, lg, kc.SlotImage.from_planes(hb), 1)
+        lg = tp.new_live_graph()
+        srcs, firsts, lasts = [], [], []
+        for k in range(n_branches):
+            na = lg.add_node(kc.Node.new(kc.NodeType.Embed(2 * k)))
+            nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(2 * k + 1)))
             first, last = add_chain(kc, lg, na, nb, sub_nodes)
-            branches.append((lg, na, first, last))
-        g = branches[0] if branches else None
-        dev = torch.device("cuda", device_index)
-        import ctypes as C
-        from kanter_core_amd import _lib
-        L = _lib.load()
-
-        def plane_tensor(handle):
-            ptr, pitch = C.c_void_p(), C.c_size_t()
-            assert L.kc_plane_device_ptr(handle, C.byref(ptr), C.byref(pitch)) == 0
-            t = multi_gpu.DevicePlaneView(ptr.value, S, S, pitch.value).tensor(dev)
-            L.kc_plane_release(handle)
-            return t
-
-        def image_of(tensors):
-            planes = []
-            for t in tensors:
-                p = C.c_void_p()
-                assert L.kc_plane_wrap(t.data_ptr(), S, S, S * 4, C.byref(p)) == 0
-                planes.append(p)
-            imgs = []
-            for p in planes:
-                im = C.c_void_p()
-                L.kc_image_gray(p, C.byref(im))
-                L.kc_plane_release(p)
-                imgs.append(kc.SlotImage(im.value))
-            return kc.combine_rgba_process(imgs + [None]), tensors  # keep the tensors alive
-
+            srcs.append((na, nb))
+            firsts.append(first)
+            lasts.append(last)
+        level = list(lasts)
+        while len(level) > 1:
+            nxt = []
+            for i in range(0, len(level) - 1, 2):
+                n = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)))
+                lg.connect(level[i], n, 0, 0)
+                lg.connect(level[i + 1], n, 0, 1)
+                nxt.append(n)
+            if len(level) & 1:
+                nxt.append(level[-1])
+            level = nxt
+        root = level[0]
+        header_group = dist.new_group(backend="gloo") if (world > 1 and args.dist_backend == "nccl") else None
+        ev = PartitionedEvaluator(lg, root, policy=kc.PartitionPolicy.Spread if args.policy == "spread" else kc.PartitionPolicy.Auto,
+                                  device=torch.device("cuda", device_index), header_group=header_group)
+        placed = {n: r for (n, r, _, _) in ev.plan.nodes}
+        mine = [k for k in range(n_branches) if placed[lasts[k]] == rank]
+        for k in range(n_branches):
+            for j, (node, seed) in enumerate(zip(srcs[k], (0x5EED0100 + k, 0x5EED0200 + k))):
+                if placed[node] == rank:
+                    planes = [splitmix_plane(seed, c, S, S) for c in range(4)]
+                    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(planes)), 2 * k + j)
+        g = (lg, None, None, root)
         keep = []
 
         def step():
-            keep.clear()
-            results = []
-            for (lg, na, first, last) in branches:
-                lg.connect(na, first, 0, 0)
-                img = lg.await_clean(last).slot_data(last, 0).image
-                results.append((img, [plane_tensor(h) for h in img.plane_handles()[:3]]))  # alpha is constant 1
-            gathered = []
-            for slot in range(most):
-                planes = results[slot][1] if slot < len(results) else [torch.zeros(S, S, device=dev) for _ in range(3)]
-                got = multi_gpu.gather_planes(planes, dst=0)
-                if rank == 0:
-                    for r in range(world):
-                        if slot < len(multi_gpu.assign_branches(n_branches, world)[r]):
-                            gathered.append(image_of(got[r]))
-            if rank == 0:
-                total = multi_gpu.fan_in([im for im, _ in gathered], lambda x, y: kc.mix_process(x, y, kc.MixType.Add))
-                total.materialize()
-                keep.append((total, gathered, results))
-            else:
-                keep.append(results)
+            for k in mine:
+                lg.connect(srcs[k][0], firsts[k], 0, 0)  # re-plugging the input dirties the branch and what joins it
+            keep[:] = [ev.evaluate()]
 
-        node_px = float(len(mine) * sub_nodes + (n_branches - 1 if rank == 0 else 0)) * S * S
-        alg_bytes = len(mine) * 36.0 * S * S + (((n_branches * 3 + 3) * 4.0 * S * S) if rank == 0 else 0.0)
-        kernel = "chain_kernel<2,4,0> + RCCL gather + chain_kernel<4,4,0>"
-        desc = "8 independent 16-node subgraphs at %dx%d f32x4, RCCL gather to rank 0, 7-node Mix(Add) tree, BASELINE config #4" % (S, S)
+        n_tree = n_branches - 1
+        node_px = float(len(mine) * sub_nodes + (n_tree if rank == ev.plan.home else 0)) * S * S
+        # per rank: its fused subgraphs (36 B/px each); home: the add tree over 8 resident RGB results -- 4 launches reading
+        # 2, 2, 3, 4 planes and writing 1 each, per channel (chains are linear and hold at most 4 distinct input planes)
+        alg_bytes = len(mine) * 36.0 * S * S + ((15 * 3 * 4.0 * S * S) if rank == ev.plan.home else 0.0)
+        kernel = "chain_kernel<2,*> per subgraph + RCCL send/recv + chain_kernel<2..4,*> add tree"
+        desc = ("8 independent 16-node subgraphs at %dx%d f32x4 placed by kc_live_graph_partition (%s), branch results sent to "
+                "the home rank over RCCL, 7-node Mix(Add) tree there, BASELINE config #4" % (S, S, args.policy))
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    counted = [0.0]  # algorithmic bytes per step of the last timed() call, as the library counted them launch by launch
 
     def warm(stepfn, warmup):
         # The first sightings of a chain program run through the interpreter while the program-specialised kernel
@@ -279,7 +272,8 @@ def main():
 
     def timed(stepfn, steps, warmup, sync_ranks=True):
         warm(stepfn, warmup)
-        launches0 = kc.stats()["kernel_launches"]
+        st0 = kc.stats()
+        launches0 = st0["kernel_launches"]
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier() if sync_ranks else torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -290,7 +284,9 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         barrier() if sync_ranks else torch.cuda.synchronize()
-        return t1 - t0, ev0.elapsed_time(ev1) * 1e-3, kc.stats()["kernel_launches"] - launches0
+        st1 = kc.stats()
+        counted[0] = (st1["algorithmic_bytes"] - st0["algorithmic_bytes"]) / float(steps)
+        return t1 - t0, ev0.elapsed_time(ev1) * 1e-3, st1["kernel_launches"] - launches0
 
     def step_spread(stepfn, steps):
         """A second, separate pass with one HIP event after EVERY step (the events cost a few us of pipeline
@@ -305,6 +301,11 @@ def main():
         return sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(steps))
 
     wall, dev_s, launches = timed(step, args.steps, args.warmup)
+    # Algorithmic bytes: the per-kernel figures of DESIGN.md section 3 summed by the library over the launches of a step
+    # (kc_stats_algorithmic_bytes).  For the headline it must equal the closed form above (36 B/px); for graphs whose
+    # fusion pattern is decided at run time (fanin: the add tree continues some of the branch chains) it is the figure.
+    formula_bytes = alg_bytes
+    alg_bytes = counted[0]
     main_step_us = step_spread(step, max(20, min(args.steps, 100)))
     total_px = node_px
     if world > 1:
@@ -344,13 +345,14 @@ def main():
         "config": {
             "workload": desc, "graph_nodes": N if args.workload == "chain32" else None, "width": S, "height": S,
             "channels": 4, "use_cache": False,
-            "parallelism": ("independent graph per GPU" if args.workload != "fanin" else "branch per GPU + RCCL gather")
+            "parallelism": ("independent graph per GPU" if args.workload != "fanin" else "branches placed by the library's partitioner + RCCL send/recv to the home rank")
             if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_step, 1.0) if launches_per_step else alg_bytes,
+            "algorithmic_bytes_per_step": alg_bytes, "closed_form_bytes_per_step": formula_bytes,
             "kernel_us": round(per_step_s / max(launches_per_step, 1.0) * 1e6, 2),
             "launches_per_step": launches_per_step,
             # separate pass, one HIP event after every step (>= 20 steps): spread of individual steps, event overhead included
@@ -418,6 +420,46 @@ def main():
         mism = int(sum((x.view(np.uint32) != y.view(np.uint32)).sum() for x, y in zip(got, ref)))
         out["parity"] = {"checked_pixels": S * rows * 4, "bit_mismatches": mism}
 
+    if rank == 0 and world == 1 and args.workload in ("mix1", "resize_blend", "fanin") and not args.no_cpu_baseline:
+        # parity of the timed graph against the oracle on the same inputs (the oracle as checker, after the timed region)
+        from oracle import oracle as orc
+        orc.set_threads(max(1, min(os.cpu_count() or 1, 16)))
+        if args.workload == "mix1":
+            ref = [orc.mix_plane("Add", host_a[c], host_b[c]) for c in range(3)]
+        elif args.workload == "resize_blend":
+            bu = [orc.resize_plane(p, S, S, "Triangle") for p in host_b[:3]]
+            ref = [orc.mix_plane("Subtract", orc.mix_plane("Multiply", orc.mix_plane("Add", host_a[c], bu[c]), host_a[c]), bu[c])
+                   for c in range(3)]
+        else:
+            parts = []
+            for k in range(n_branches):
+                ha = [splitmix_plane(0x5EED0100 + k, c, S, S) for c in range(3)]
+                hb = [splitmix_plane(0x5EED0200 + k, c, S, S) for c in range(3)]
+                parts.append(orc.chain32(ha, hb, sub_nodes)[:3])
+            while len(parts) > 1:
+                nxt = [[orc.mix_plane("Add", parts[i][c], parts[i + 1][c]) for c in range(3)] for i in range(0, len(parts) - 1, 2)]
+                if len(parts) & 1:
+                    nxt.append(parts[-1])
+                parts = nxt
+            ref = parts[0]
+        orc.set_threads(1)
+        ref = list(ref) + [np.ones((S, S), np.float32)]
+        got = g[0].slot_data(g[3], 0).image.planes()
+        nan_ok = lambda x, y: (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))  # noqa: E731
+        mism = int(sum((~nan_ok(x, y)).sum() for x, y in zip(got, ref)))
+        out["parity"] = {"checked_pixels": S * S * 4, "bit_mismatches": mism}
+
+    if args.workload == "fanin":
+        st = dict(ev.stats)
+        st["transfers_in_plan"] = len(ev.plan.transfers)
+        st["branches"] = len(mine)
+        if world > 1:
+            allst = [None] * world
+            dist.all_gather_object(allst, st, group=header_group)
+        else:
+            allst = [st]
+        out["per_rank"] = [{k: (round(v, 6) if isinstance(v, float) else v) for k, v in x.items()} for x in allst]
+        out["multi_gpu_measured"] = world > 1 and args.dist_backend == "nccl"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -86,6 +86,7 @@ typedef struct kc_image kc_image;
 typedef struct kc_node_graph kc_node_graph;
 typedef struct kc_live_graph kc_live_graph;
 typedef struct kc_tex_pro kc_tex_pro;
+typedef struct kc_partition kc_partition;   /* multi-GPU placement plan of one graph evaluation */
 
 /* Size, src/slot_data.rs:4-30 */
 typedef struct kc_size { uint32_t width, height; } kc_size;
@@ -128,6 +129,9 @@ KC_API int kc_set_fusion(int enabled);
 KC_API int kc_get_fusion(void);
 /* Pool statistics: bytes currently handed out, bytes cached for reuse, kernels launched. */
 KC_API int kc_stats(uint64_t *bytes_in_use, uint64_t *bytes_cached, uint64_t *kernel_launches);
+/* Algorithmic HBM bytes of every kernel launched so far: per launch, each resident input plane read once and each
+ * result plane written once (what a roofline divides by; fused intermediates and constant planes cost nothing). */
+KC_API int kc_stats_algorithmic_bytes(uint64_t *bytes);
 KC_API int kc_pool_trim(void);
 /* Run-time specialisation of the fused Mix-chain kernel.  A chain of N Mix nodes (src/node/mix.rs:136-192
  * applied N times) normally runs through a step-table interpreter; a program that keeps coming back is also
@@ -293,6 +297,42 @@ KC_API int kc_live_graph_edges(const kc_live_graph *lg, kc_edge *edges, uint32_t
 /* Base directory that relative Image / Write paths resolve against (the reference resolves them
  * against the process's working directory). */
 KC_API int kc_live_graph_set_base_dir(kc_live_graph *lg, const char *dir);
+
+/* ========================================================================================== *
+ * Multi-GPU: one process per GPU, every process holds the same graph.  The reference runs every ready
+ * node on its own thread and needs nothing but the parents' slot data to do so (src/engine.rs:213-275,
+ * :288); here the same rule lets independent branches run on different GPUs.  kc_live_graph_partition
+ * derives, from the graph alone (so every rank computes the same answer without communicating), which rank
+ * evaluates which ancestor of `root` and which slots cross a rank boundary.  The host moves those slots
+ * (RCCL send / recv of the planes: kc_plane_device_ptr on the producer's rank, kc_plane_alloc +
+ * kc_image_gray / kc_image_rgba on the consumer's) and hands them over with kc_live_graph_import_slot_data;
+ * every rank calls kc_live_graph_await_clean only on nodes placed on it.  INTEGRATION.md shows the loop.
+ * ========================================================================================== */
+typedef enum kc_partition_policy {
+    KC_PARTITION_AUTO = 0,   /* list scheduling by estimated finish time, transfers charged (one RGBA 4096^2 slot over
+                              * xGMI ~ 12 fused Mix chains): keeps small graphs on one GPU */
+    KC_PARTITION_SPREAD = 1  /* transfers not charged: independent branches fill all ranks */
+} kc_partition_policy;
+typedef enum kc_node_kind {
+    KC_KIND_SOURCE = 0,     /* Embed / Image / Input*: data somebody put there; lives on `rank` */
+    KC_KIND_REPLICATED = 1, /* no source among its ancestors (Value nodes and constants built from them):
+                             * evaluated on every rank that needs it, never sent; rank = -1 */
+    KC_KIND_COMPUTE = 2     /* evaluated on `rank` only */
+} kc_node_kind;
+typedef struct kc_placement { uint32_t node_id; int32_t rank; int32_t component; int32_t kind; } kc_placement;
+/* One slot moving from the rank that produced it to ONE consumer rank; a slot consumed on several ranks (a
+ * broadcast) appears once per destination, consecutively.  Transfers are listed in the order every rank must
+ * work through them; `level` = how many rank boundaries the data has crossed before (0 for branch results). */
+typedef struct kc_transfer { uint32_t node_id, slot_id; int32_t src_rank, dst_rank; int32_t level; } kc_transfer;
+KC_API int kc_live_graph_partition(kc_live_graph *lg, uint32_t root_node_id, int world_size, int policy, kc_partition **out);
+KC_API int kc_partition_free(kc_partition *p);
+KC_API int kc_partition_info(const kc_partition *p, int *world_size, int *home_rank, int *levels);
+/* Ancestors of the root (root included) in topological order, with their placement. */
+KC_API int kc_partition_nodes(const kc_partition *p, kc_placement *out, uint32_t cap, uint32_t *count);
+KC_API int kc_partition_transfers(const kc_partition *p, kc_transfer *out, uint32_t cap, uint32_t *count);
+/* Stores `image` (+1 ref) as slot `slot_id` of `node_id` and marks the node Clean, exactly as the engine does with
+ * the result of a finished node (src/engine.rs:34-57): the receiving side of a transfer. */
+KC_API int kc_live_graph_import_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image *image);
 
 #ifdef __cplusplus
 }

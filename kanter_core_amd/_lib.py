@@ -30,6 +30,15 @@ class kc_node_desc(C.Structure):
                 ("policy_slot", C.c_uint32), ("policy_size", kc_size), ("resize_filter", C.c_int32)]
 
 
+class kc_placement(C.Structure):
+    _fields_ = [("node_id", C.c_uint32), ("rank", C.c_int32), ("component", C.c_int32), ("kind", C.c_int32)]
+
+
+class kc_transfer(C.Structure):
+    _fields_ = [("node_id", C.c_uint32), ("slot_id", C.c_uint32), ("src_rank", C.c_int32), ("dst_rank", C.c_int32),
+                ("level", C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/kanter_core_amd.h declares.
 SIGNATURES = {
     "kc_init": (C.c_int, [C.c_int]),
@@ -48,7 +57,14 @@ SIGNATURES = {
     "kc_specialize_wait": (C.c_int, []),
     "kc_specialize_stats": (C.c_int, [C.POINTER(C.c_uint64)] * 4),
     "kc_specialize_compile_check": (C.c_int, [c_u32p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "kc_stats_algorithmic_bytes": (C.c_int, [C.POINTER(C.c_uint64)]),
     "kc_pool_trim": (C.c_int, []),
+    "kc_live_graph_partition": (C.c_int, [c_vp, C.c_uint32, C.c_int, C.c_int, C.POINTER(c_vp)]),
+    "kc_partition_free": (C.c_int, [c_vp]),
+    "kc_partition_info": (C.c_int, [c_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kc_partition_nodes": (C.c_int, [c_vp, C.POINTER(kc_placement), C.c_uint32, c_u32p]),
+    "kc_partition_transfers": (C.c_int, [c_vp, C.POINTER(kc_transfer), C.c_uint32, c_u32p]),
+    "kc_live_graph_import_slot_data": (C.c_int, [c_vp, C.c_uint32, C.c_uint32, c_vp]),
     "kc_plane_alloc": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(c_vp)]),
     "kc_plane_const": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(c_vp)]),
     "kc_plane_wrap": (C.c_int, [c_vp, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(c_vp)]),

@@ -120,7 +120,9 @@ def specialize_compile_check(words, n_in, start_src=0, flat=True):
 def stats():
     a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
     _check(_lib.load().kc_stats(C.byref(a), C.byref(b), C.byref(c)))
-    return {"bytes_in_use": a.value, "bytes_cached": b.value, "kernel_launches": c.value}
+    d = C.c_uint64()
+    _check(_lib.load().kc_stats_algorithmic_bytes(C.byref(d)))
+    return {"bytes_in_use": a.value, "bytes_cached": b.value, "kernel_launches": c.value, "algorithmic_bytes": d.value}
 
 
 # ------------------------------------------------------------------ small value types
@@ -822,9 +824,64 @@ class LiveGraph:
                                                                  int(embedded_id)))
         return EmbeddedSlotDataId(embedded_id)
 
+    def partition(self, root_node_id, world_size, policy=0):
+        """Multi-GPU placement of the evaluation of `root_node_id` over `world_size` ranks (csrc/partition.cpp);
+        the same on every rank.  policy: PartitionPolicy.Auto / .Spread."""
+        h = C.c_void_p()
+        _check(_lib.load().kc_live_graph_partition(self._h, int(root_node_id), int(world_size), int(policy), C.byref(h)))
+        return Partition(h.value)
+
+    def import_slot_data(self, node_id, slot_id, image):
+        """The receiving side of a transfer: `image` becomes slot `slot_id` of `node_id`, which is Clean afterwards."""
+        _check(_lib.load().kc_live_graph_import_slot_data(self._h, int(node_id), int(slot_id), image._h))
+
     def add_input_slot_data(self, slot_data):
         _check(_lib.load().kc_live_graph_add_input_slot_data(self._h, slot_data.node_id, slot_data.slot_id,
                                                              slot_data.image._h))
+
+
+class PartitionPolicy:
+    Auto, Spread = 0, 1
+
+
+class NodeKind:
+    Source, Replicated, Compute = 0, 1, 2
+
+
+class Partition:
+    """Placement plan of one graph evaluation over `world` ranks (include/kanter_core_amd.h, "Multi-GPU").
+    nodes: [(node_id, rank, component, kind)] in topological order, rank -1 = replicated;
+    transfers: [(node_id, slot_id, src_rank, dst_rank, level)] in execution order."""
+
+    def __init__(self, handle):
+        from ._lib import kc_placement, kc_transfer
+        L = _lib.load()
+        self._h = C.c_void_p(handle)
+        w, hm, lv = C.c_int(), C.c_int(), C.c_int()
+        _check(L.kc_partition_info(self._h, C.byref(w), C.byref(hm), C.byref(lv)))
+        self.world, self.home, self.levels = w.value, hm.value, lv.value
+        n = C.c_uint32()
+        _check(L.kc_partition_nodes(self._h, None, 0, C.byref(n)))
+        buf = (kc_placement * max(n.value, 1))()
+        _check(L.kc_partition_nodes(self._h, buf, n.value, C.byref(n)))
+        self.nodes = [(buf[i].node_id, buf[i].rank, buf[i].component, buf[i].kind) for i in range(n.value)]
+        _check(L.kc_partition_transfers(self._h, None, 0, C.byref(n)))
+        tb = (kc_transfer * max(n.value, 1))()
+        _check(L.kc_partition_transfers(self._h, tb, n.value, C.byref(n)))
+        self.transfers = [(tb[i].node_id, tb[i].slot_id, tb[i].src_rank, tb[i].dst_rank, tb[i].level) for i in range(n.value)]
+
+    def __del__(self):
+        try:
+            _lib.load().kc_partition_free(self._h)
+        except Exception:
+            pass
+
+    def rank_of(self, node_id):
+        return next(r for (n, r, _, _) in self.nodes if n == node_id)
+
+    def local_nodes(self, rank):
+        """Nodes this rank evaluates: its own plus the replicated ones."""
+        return [n for (n, r, _, _) in self.nodes if r == rank or r == -1]
 
 
 class TextureProcessor:

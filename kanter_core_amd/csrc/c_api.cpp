@@ -242,6 +242,16 @@ try {
 }
 KC_CATCH
 
+int kc_stats_algorithmic_bytes(uint64_t *bytes)
+try {
+    KC_ARG(bytes);
+    Context &c = ctx();
+    Lock lk(c.mu);
+    *bytes = c.alg_bytes;
+    return KC_OK;
+}
+KC_CATCH
+
 int kc_pool_trim(void)
 try {
     KC_TRY(need_init());
@@ -1109,6 +1119,57 @@ try {
     image_retain(image);
     lg->input_slot_datas.push_back(SlotData{ node_id, slot_id, image });
     return KC_OK;
+}
+KC_CATCH
+
+// ---------------------------------------------------------------- multi-GPU placement (partition.cpp)
+int kc_live_graph_partition(kc_live_graph *lg, uint32_t root, int world, int policy, kc_partition **out)
+try {
+    LG_LOCK(lg);
+    KC_ARG(out);
+    return partition_plan(*lg, root, world, policy, out);
+}
+KC_CATCH
+
+int kc_partition_free(kc_partition *p)
+{
+    delete p;
+    return KC_OK;
+}
+
+int kc_partition_info(const kc_partition *p, int *world, int *home, int *levels)
+try {
+    KC_ARG(p);
+    if (world) *world = p->world;
+    if (home) *home = p->home;
+    if (levels) *levels = p->n_levels;
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_partition_nodes(const kc_partition *p, kc_placement *out, uint32_t cap, uint32_t *count)
+try {
+    KC_ARG(p && count);
+    *count = (uint32_t)p->nodes.size();
+    for (uint32_t i = 0; out && i < cap && i < *count; ++i) out[i] = p->nodes[i];
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_partition_transfers(const kc_partition *p, kc_transfer *out, uint32_t cap, uint32_t *count)
+try {
+    KC_ARG(p && count);
+    *count = (uint32_t)p->xfers.size();
+    for (uint32_t i = 0; out && i < cap && i < *count; ++i) out[i] = p->xfers[i];
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_live_graph_import_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image *image)
+try {
+    LG_LOCK(lg);
+    KC_ARG(image);
+    return lg->import_slot_data(node_id, slot_id, image);
 }
 KC_CATCH
 

@@ -110,6 +110,7 @@ struct Context {
     int resize_tile_h = 0;  // > 0: force this tile height for 256-wide tiles (KC_RESIZE_TILE_H, tuning only)
     std::multimap<size_t, void *> free_blocks;
     uint64_t bytes_in_use = 0, bytes_cached = 0, launches = 0;
+    uint64_t alg_bytes = 0;  // algorithmic HBM bytes of every kernel launched so far (DESIGN.md section 3's per-kernel figures)
     std::map<std::tuple<uint32_t, uint32_t, int>, TapsEntry> taps;
     // Within one graph evaluation the same plane resized to the same size with the same filter is
     // computed once (the reference resamples it per consuming node, src/shared.rs:152-207; planes
@@ -331,12 +332,21 @@ struct kc_live_graph {
     int remove_edge(kc_edge e);
     int disconnect_slot(uint32_t id, int side, uint32_t slot);
     int ensure_clean(uint32_t id);
+    int import_slot_data(uint32_t node, uint32_t slot, kc_image *image);  // partition.cpp
     int await_clean(uint32_t id);
     int update();
     int process_one(uint32_t id);
 };
 
+// Multi-GPU placement plan (partition.cpp)
+struct kc_partition {
+    int world = 1, home = 0, n_levels = 1;
+    std::vector<kc_placement> nodes;  // topological order
+    std::vector<kc_transfer> xfers;   // execution order: level, producer's topological position, slot, destination
+};
+
 namespace kc {
+int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out);
 // process_node, src/node/node_type.rs:213-248: inputs in edge insertion order.
 int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData> &inputs,
                  const std::vector<kc_edge> &edges, std::vector<SlotData> &out);

@@ -87,7 +87,10 @@ int image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_
         // the caller may free `host` as soon as we return (pageable memory can be DMA'd in place)
         if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
         if (e != hipSuccess) s = hip_fail(e, "image_from_u8");
-        else c.launches++;
+        else {
+            c.launches++;
+            c.alg_bytes += (uint64_t)w * h * channels * 5;  // 1 B read + 4 B written per sample
+        }
     }
     pool_free(staging, block);
     if (s == KC_OK) *out = image_new(4, p);
@@ -113,6 +116,9 @@ int image_to_u8(kc_image *img, bool srgb, uint8_t *host)
                                 (uint8_t *)staging, c.stream);
     if (e == hipSuccess) {
         c.launches++;
+        int resident = 0;
+        for (int i = 0; i < (img->is_rgba() ? 4 : 1); ++i) resident += o[i].ptr != nullptr;
+        c.alg_bytes += (uint64_t)w * h * 4 * (resident + 1);
         e = hipMemcpyAsync(host, staging, nbytes, hipMemcpyDeviceToHost, c.stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
@@ -314,7 +320,10 @@ int height_to_normal_process(kc_image *in, kc_image **out)
         hipError_t e = launch_height_to_normal(src->dptr, (uint32_t)(src->pitch / 4), w, h, p[0]->dptr, p[1]->dptr,
                                                p[2]->dptr, (uint32_t)(p[0]->pitch / 4), c.stream);
         if (e != hipSuccess) s = hip_fail(e, "launch_height_to_normal");
-        else c.launches++;
+        else {
+            c.launches++;
+            c.alg_bytes += (uint64_t)w * h * 16;  // 4 B read + 12 B written per pixel
+        }
     }
     if (s == KC_OK) {
         p[3] = plane_new_const(w, h, 1.0f);  // from_buffers_rgb appends a ones plane (slot_image.rs:90-102)

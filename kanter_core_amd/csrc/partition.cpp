@@ -1,0 +1,273 @@
+// Multi-GPU placement of a graph evaluation: which rank (one process per GPU) evaluates which node, and
+// which slots have to move between ranks.
+//
+// The reference has no distributed layer; what makes one possible is its readiness rule -- a node needs
+// nothing but its parents' slot data (src/engine.rs:213-275) -- so independent branches of a graph can be
+// evaluated anywhere and only the edges that cross a rank boundary carry data.  This file computes that cut,
+// deterministically from the graph alone, so every rank (each holds the same NodeGraph) derives the same plan
+// without talking to the others; the host above the C ABI moves the planes (RCCL send/recv over xGMI, see
+// kanter_core_amd/multi_gpu.py and INTEGRATION.md) and hands them back with kc_live_graph_import_slot_data.
+//
+//   1. the ancestors of the requested node, in topological order (a cycle is an error);
+//   2. node kinds: SOURCE (Embed / Image / Input*: holds data somebody embedded), REPLICATED (no source among
+//      its ancestors -- Value nodes and what is built from them: constants, evaluated wherever needed, never
+//      sent), COMPUTE (everything else);
+//   3. components: a COMPUTE node continues its parent's component when it is that parent's only COMPUTE child
+//      and has no other COMPUTE parent; fan-in and fan-out both start a new component.  (Sources do not count
+//      as parents here: B feeding every other node of a chain must not cut the chain.)
+//   4. placement: components downstream of a fan-in ("join region") go to the home rank, so that all branch
+//      results converge on ONE rank over distinct xGMI links at the same time (a gather) instead of hopping
+//      through a tree of ranks; the branch components are list-scheduled over the ranks by estimated finish
+//      time.  KC_PARTITION_SPREAD ignores transfer cost in that estimate (use every GPU; the BASELINE multi-GPU
+//      configs), KC_PARTITION_AUTO charges it -- and then keeps small graphs on one GPU, which is the right
+//      answer more often than not: one 4096x4096 RGBA slot over a 153 GB/s link (1.3 ms) costs as much as a
+//      dozen fused Mix chains of any length (105 us each at 5.7 TB/s);
+//   5. sources live on the lowest rank that consumes them; every other edge from a non-replicated producer to a
+//      consumer on another rank is a transfer.  One slot consumed on several ranks appears once per
+//      destination, consecutively: a broadcast.
+#include <algorithm>
+
+#include "kc_runtime.hpp"
+
+using namespace kc;
+
+namespace kc {
+
+namespace {
+
+enum Kind { SOURCE = 0, REPLICATED = 1, COMPUTE = 2 };
+
+bool is_source(const Node &n) { return n.type == KC_NODE_EMBED || n.type == KC_NODE_IMAGE || n.is_input(); }
+
+// relative cost of evaluating a node (one fused Mix chain ~ 1 whatever its length when nothing is cached)
+double node_weight(const Node &n, bool use_cache)
+{
+    switch (n.type) {
+    case KC_NODE_MIX: return use_cache ? 1.0 : 1.0 / 16.0;
+    case KC_NODE_HEIGHT_TO_NORMAL: return 1.0;
+    case KC_NODE_GRAPH: return 4.0;
+    case KC_NODE_WRITE: return 4.0;
+    default: return 0.0;  // aliasing nodes
+    }
+}
+
+const double kTransferCost = 12.0;  // one RGBA slot over one xGMI link, in the units of node_weight
+
+}  // namespace
+
+int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out)
+{
+    const NodeGraph &g = lg.g;
+    if (!g.find(root)) return KC_ERR_INVALID_NODE_ID;
+    if (world < 1 || world > 1024 || (policy != KC_PARTITION_AUTO && policy != KC_PARTITION_SPREAD)) {
+        set_error("partition: world must be 1..1024 and policy KC_PARTITION_AUTO or KC_PARTITION_SPREAD");
+        return KC_ERR_INVALID_ARG;
+    }
+    // ---- 1. ancestors in topological order (iterative post-order; an edge into the stack is a cycle)
+    std::vector<uint32_t> topo;
+    std::map<uint32_t, int> mark;  // 1 = on the stack, 2 = done
+    {
+        struct Frame {
+            uint32_t id;
+            std::vector<uint32_t> parents;
+            size_t next;
+        };
+        std::vector<Frame> st;
+        st.push_back(Frame{ root, g.get_parents(root), 0 });
+        mark[root] = 1;
+        while (!st.empty()) {
+            Frame &f = st.back();
+            if (f.next == f.parents.size()) {
+                mark[f.id] = 2;
+                topo.push_back(f.id);
+                st.pop_back();
+                continue;
+            }
+            const uint32_t p = f.parents[f.next++];
+            if (!g.find(p)) continue;
+            const int m = mark[p];
+            if (m == 2) continue;
+            if (m == 1) {
+                set_error("graph has a cycle through node " + std::to_string(p));
+                return KC_ERR_NODE_PROCESSING;
+            }
+            mark[p] = 1;
+            st.push_back(Frame{ p, g.get_parents(p), 0 });
+        }
+    }
+    const size_t n = topo.size();
+    std::map<uint32_t, size_t> pos;
+    for (size_t i = 0; i < n; ++i) pos[topo[i]] = i;
+    auto needed = [&](uint32_t id) { return pos.count(id) != 0; };
+
+    // ---- 2. kinds
+    std::vector<int> kind(n, COMPUTE);
+    for (size_t i = 0; i < n; ++i) {
+        const Node &nd = *g.find(topo[i]);
+        if (is_source(nd)) {
+            kind[i] = SOURCE;
+        } else if (nd.type == KC_NODE_GRAPH || nd.type == KC_NODE_WRITE) {
+            kind[i] = COMPUTE;  // a nested graph may read files; a Write has a side effect: exactly one rank runs it
+        } else {
+            bool all_repl = true;
+            for (uint32_t p : g.get_parents(topo[i]))
+                if (needed(p)) all_repl &= kind[pos[p]] == REPLICATED;
+            kind[i] = all_repl ? REPLICATED : COMPUTE;
+        }
+    }
+
+    // ---- 3. components over the COMPUTE nodes
+    std::vector<std::vector<size_t>> cparents(n), cchildren(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (kind[i] != COMPUTE) continue;
+        for (uint32_t p : g.get_parents(topo[i])) {
+            if (!needed(p) || kind[pos[p]] != COMPUTE) continue;
+            cparents[i].push_back(pos[p]);
+            cchildren[pos[p]].push_back(i);
+        }
+    }
+    std::vector<int> comp(n, -1);
+    struct Comp {
+        std::vector<size_t> members;
+        std::set<int> inputs;
+        double weight = 0.0;
+        bool join = false;
+        int rank = -1, level = 0;
+        double finish = 0.0;
+    };
+    std::vector<Comp> comps;
+    for (size_t i = 0; i < n; ++i) {
+        if (kind[i] != COMPUTE) continue;
+        if (cparents[i].size() == 1 && cchildren[cparents[i][0]].size() == 1) {
+            comp[i] = comp[cparents[i][0]];
+        } else {
+            comp[i] = (int)comps.size();
+            comps.emplace_back();
+        }
+        Comp &c = comps[comp[i]];
+        c.members.push_back(i);
+        c.weight += node_weight(*g.find(topo[i]), lg.use_cache);
+        for (size_t p : cparents[i])
+            if (comp[p] != comp[i]) c.inputs.insert(comp[p]);
+    }
+    // join region: fan-in components and everything downstream of one (components are numbered in
+    // topological order, so one forward pass settles it)
+    for (auto &c : comps) {
+        c.join = c.inputs.size() >= 2;
+        for (int i : c.inputs) c.join |= comps[i].join;
+    }
+
+    // ---- 4. placement
+    const int home = 0;
+    std::vector<double> avail((size_t)world, 0.0);
+    // A branch result that a join consumes has to reach the home rank: KC_PARTITION_AUTO charges that hop to every
+    // placement away from home (SPREAD does not look at transfer costs at all).
+    std::vector<char> feeds_join(comps.size(), 0);
+    for (auto &c : comps)
+        if (c.join)
+            for (int i : c.inputs) feeds_join[(size_t)i] = 1;
+    // branch components first (they never depend on a join), then the join region: a join placed early would
+    // make the home rank look busy until its remote inputs could have arrived and push every later branch away
+    for (int pass = 0; pass < 2; ++pass)
+        for (auto &c : comps) {
+            if (c.join != (pass == 1)) continue;
+            const double w = std::max(c.weight, 1.0 / 64.0);
+            int best = home;
+            if (!c.join) {
+                double best_finish = 0.0;
+                int best_local = -1;
+                for (int r = 0; r < world; ++r) {
+                    double ready = 0.0;
+                    int local = 0;
+                    for (int i : c.inputs) {
+                        const bool same = comps[i].rank == r;
+                        local += same;
+                        ready = std::max(ready, comps[i].finish + ((same || policy == KC_PARTITION_SPREAD) ? 0.0 : kTransferCost));
+                    }
+                    double finish = std::max(avail[(size_t)r], ready) + w;
+                    if (policy == KC_PARTITION_AUTO && feeds_join[(size_t)(&c - comps.data())] && r != home) finish += kTransferCost;
+                    if (best_local < 0 || finish < best_finish - 1e-12 || (finish < best_finish + 1e-12 && local > best_local)) {
+                        best = r;
+                        best_finish = finish;
+                        best_local = local;
+                    }
+                }
+            }
+            double ready = 0.0;
+            for (int i : c.inputs) {
+                ready = std::max(ready, comps[i].finish + (comps[i].rank == best ? 0.0 : kTransferCost));
+                c.level = std::max(c.level, comps[i].level + (comps[i].rank == best ? 0 : 1));
+            }
+            c.rank = best;
+            c.finish = std::max(avail[(size_t)best], ready) + w;
+            avail[(size_t)best] = c.finish;
+        }
+
+    // ---- 5. sources, transfers
+    std::vector<int> rank(n, -1);
+    for (size_t i = 0; i < n; ++i)
+        if (kind[i] == COMPUTE) rank[i] = comps[comp[i]].rank;
+    auto consumers = [&](size_t i) {
+        std::vector<size_t> c;
+        for (uint32_t ch : g.get_children(topo[i]))
+            if (needed(ch) && kind[pos[ch]] == COMPUTE) c.push_back(pos[ch]);
+        return c;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        if (kind[i] != SOURCE) continue;
+        int r = -1;
+        for (size_t c : consumers(i)) r = r < 0 ? rank[c] : std::min(r, rank[c]);
+        rank[i] = r < 0 ? home : r;  // a source nobody computes on is the requested node itself
+    }
+    kc_partition *P = new kc_partition();
+    P->world = world;
+    P->home = home;
+    for (size_t i = 0; i < n; ++i)
+        P->nodes.push_back(kc_placement{ topo[i], kind[i] == REPLICATED ? -1 : rank[i], kind[i] == COMPUTE ? comp[i] : -1, kind[i] });
+    struct Key {
+        int level;
+        size_t ppos;
+        uint32_t slot;
+        int dst;
+        bool operator<(const Key &o) const { return std::tie(level, ppos, slot, dst) < std::tie(o.level, o.ppos, o.slot, o.dst); }
+    };
+    std::set<Key> seen;
+    int levels = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (kind[i] != COMPUTE) continue;
+        for (auto &e : g.edges_into(topo[i])) {
+            if (!needed(e.output_id)) continue;
+            const size_t p = pos[e.output_id];
+            if (kind[p] == REPLICATED || rank[p] == rank[i]) continue;
+            const int level = kind[p] == COMPUTE ? comps[comp[p]].level : 0;
+            seen.insert(Key{ level, p, e.output_slot, rank[i] });
+            levels = std::max(levels, level + 1);
+        }
+    }
+    for (auto &k : seen) P->xfers.push_back(kc_transfer{ topo[k.ppos], k.slot, rank[k.ppos], k.dst, k.level });
+    P->n_levels = std::max(levels, 1);
+    *out = P;
+    return KC_OK;
+}
+
+}  // namespace kc
+
+// Received slot data takes the place of evaluating the producer on this rank (engine.rs:34-57 stores a
+// finished node's outputs the same way): the slot is replaced and the node is Clean.
+int kc_live_graph::import_slot_data(uint32_t node, uint32_t slot, kc_image *image)
+{
+    if (!g.find(node)) return KC_ERR_INVALID_NODE_ID;
+    for (size_t i = slot_datas.size(); i-- > 0;)
+        if (slot_datas[i].node_id == node && slot_datas[i].slot_id == slot) {
+            image_release(slot_datas[i].image);
+            slot_datas.erase(slot_datas.begin() + (long)i);
+        }
+    image_retain(image);
+    slot_datas.push_back(SlotData{ node, slot, image });
+    // new data for this node: whatever was computed from the old one is out of date (the same propagation a
+    // connect() triggers, src/live_graph.rs:515-537), the node itself is up to date
+    for (uint32_t c : g.get_children(node)) KC_TRY(set_state(c, KC_STATE_DIRTY));
+    node_state[node] = KC_STATE_CLEAN;
+    changed.insert(node);
+    return KC_OK;
+}

@@ -264,6 +264,7 @@ static int resize_run(kc_plane *const *srcs, kc_plane *const *dsts, int n, int f
                                              t.tile_h, t.ncp, c.stream);
             if (e != hipSuccess) return hip_fail(e, "launch_resize_lds");
             c.launches++;
+            c.alg_bytes += (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height);
             return KC_OK;
         }
     }
@@ -279,6 +280,7 @@ static int resize_run(kc_plane *const *srcs, kc_plane *const *dsts, int n, int f
         plane_release(tmp);
         if (e != hipSuccess) return hip_fail(e, "launch_resize two-pass");
         c.launches += 2;
+        c.alg_bytes += 4 * ((uint64_t)s0->w * s0->h + 2 * (uint64_t)s0->w * size.height + (uint64_t)size.width * size.height);
     }
     return KC_OK;
 }

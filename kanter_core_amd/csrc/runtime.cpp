@@ -422,6 +422,17 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
         }
     }
     c.launches++;
+    {
+        // algorithmic bytes of this launch: every resident input plane once, the result once, per channel; a
+        // resampled operand costs its (small) source instead of a full-size plane
+        uint64_t px = (uint64_t)p0->w * p0->h, bytes = 0;
+        for (int b = 0; b < batch; ++b) {
+            const uint32_t resident = P.n_in - (bc.sampled[b] ? 1u : 0u);
+            bytes += 4 * px * (resident + 1);
+            if (bc.sampled[b]) bytes += 4 * (uint64_t)bc.sampled[b]->rz_src->w * bc.sampled[b]->rz_src->h;
+        }
+        c.alg_bytes += bytes;
+    }
     for (int b = 0; b < batch; ++b) {
         kc_plane *p = planes[b];
         Chain *old = p->chain;
@@ -515,6 +526,7 @@ int plane_materialize(kc_plane *p)
             return hip_fail(e, "launch_fill");
         }
         ctx().launches++;
+        ctx().alg_bytes += (uint64_t)p->w * p->h * 4;
         p->kind = kc_plane::MEM;
         p->dptr = m->dptr;
         p->pitch = m->pitch;

@@ -1,27 +1,26 @@
-"""The N > 1 path on CPU: world_size-2 (and 3) `gloo` processes exercise branch assignment, row
-bands, the plane gather and the fixed-order fan-in tree that bench.py --workload fanin runs over
-RCCL.  (Pixel work itself needs the GPU; here the combine callback is a plain tensor add so only
-the placement / exchange logic is under test.)"""
+"""The N > 1 path on CPU: world_size-2 and -3 `gloo` processes run the library's partitioner
+(kc_live_graph_partition, host-only: no GPU needed) on real NodeGraph JSON -- a graph with a diamond, a fan-in
+and a slot that has consumers on two ranks (a broadcast) -- and the exchange loop of multi_gpu.PartitionedEvaluator
+with REAL pixel work on every rank: the slot store is the CPU oracle's literal process_node (tests may use the
+oracle as a checker), planes cross rank boundaries over gloo, and the result on the home rank must equal a
+single-process evaluation bit for bit.  A rank that touched a node the plan did not place on it fails loudly: each
+rank only holds the source images the plan gives it."""
+import json
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from kanter_core_amd.multi_gpu import assign_branches, fan_in, gather_planes, row_bands
+import kanter_core_amd as kc
+from golden_graphs import G
+from kanter_core_amd.multi_gpu import PartitionedEvaluator, row_bands
+from util import splitmix_plane
 
-
-def test_assign_branches_partitions_everything():
-    assert assign_branches(8, 8) == [[i] for i in range(8)]
-    assert assign_branches(8, 2) == [[0, 1, 2, 3], [4, 5, 6, 7]]
-    assert assign_branches(8, 3) == [[0, 1, 2], [3, 4, 5], [6, 7]]
-    assert assign_branches(2, 4) == [[0], [1], [], []]
-    for n in range(0, 20):
-        for w in range(1, 9):
-            flat = [b for r in assign_branches(n, w) for b in r]
-            assert flat == list(range(n))
+H, W = 20, 24
 
 
 def test_row_bands_cover_the_plane():
@@ -35,16 +34,246 @@ def test_row_bands_cover_the_plane():
             assert all(bands[i][1] == bands[i + 1][0] for i in range(w - 1))
 
 
-def test_fan_in_order_is_fixed():
-    order = []
+# ------------------------------------------------------------------------------------------ graphs
+def diamond_fanin_broadcast_graph():
+    """E0, E1, E2 embedded RGBA images.
+       branch A:  a1 = E0 + E1;  a2 = 1 - a1
+       prefix P:  p1 = E2 * E2                          (fan-out: consumed by b1 AND c1 -> a broadcast when they
+       branch B:  b1 = p1 + E0                           land on different ranks; E0 is also read by branch A)
+       branch C:  c1 = p1 - E1;  c2 = HeightToNormal(Separate(c1).R)
+       joins:     j1 = a2 + b1;  j2 = j1 * c2  (diamond over p1);  out = OutputRgba(j2)"""
+    g = G()
+    e = [g.add({"Embed": i}) for i in range(3)]
+    one = g.add({"Value": 1.0})
+    white = g.add("CombineRgba")
+    for s in range(3):
+        g.connect(one, white, 0, s)
+    a1 = g.add({"Mix": "Add"})
+    g.connect(e[0], a1, 0, 0)
+    g.connect(e[1], a1, 0, 1)
+    a2 = g.add({"Mix": "Subtract"})
+    g.connect(white, a2, 0, 0)
+    g.connect(a1, a2, 0, 1)
+    p1 = g.add({"Mix": "Multiply"})
+    g.connect(e[2], p1, 0, 0)
+    g.connect(e[2], p1, 0, 1)
+    b1 = g.add({"Mix": "Add"})
+    g.connect(p1, b1, 0, 0)
+    g.connect(e[0], b1, 0, 1)
+    c1 = g.add({"Mix": "Subtract"})
+    g.connect(p1, c1, 0, 0)
+    g.connect(e[1], c1, 0, 1)
+    sep = g.add("SeparateRgba")
+    g.connect(c1, sep, 0, 0)
+    c2 = g.add("HeightToNormal")
+    g.connect(sep, c2, 0, 0)
+    j1 = g.add({"Mix": "Add"})
+    g.connect(a2, j1, 0, 0)
+    g.connect(b1, j1, 0, 1)
+    j2 = g.add({"Mix": "Multiply"})
+    g.connect(j1, j2, 0, 0)
+    g.connect(c2, j2, 0, 1)
+    out = g.add({"OutputRgba": "out"})
+    g.connect(j2, out, 0, 0)
+    names = dict(e0=e[0], e1=e[1], e2=e[2], one=one, white=white, a1=a1, a2=a2, p1=p1, b1=b1, c1=c1, sep=sep, c2=c2,
+                 j1=j1, j2=j2, out=out)
+    return g.dict(), out, names
 
-    def combine(a, b):
-        order.append((a, b))
-        return "(%s+%s)" % (a, b)
 
-    assert fan_in(list("abcdefgh"), combine) == "(((a+b)+(c+d))+((e+f)+(g+h)))"
-    assert fan_in(list("abc"), combine) == "((a+b)+c)"
-    assert fan_in(["x"], combine) == "x"
+def fanin_graph(n_branches=8, n_nodes=4):
+    """BASELINE config #4's shape at toy size: n independent chains (own sources 2k, 2k+1) + a Mix(Add) tree."""
+    g = G()
+    lasts = []
+    for k in range(n_branches):
+        a, b = g.add({"Embed": 2 * k}), g.add({"Embed": 2 * k + 1})
+        one = g.add({"Value": 1.0})
+        white = g.add("CombineRgba")
+        for s in range(3):
+            g.connect(one, white, 0, s)
+        prev = a
+        for i in range(1, n_nodes + 1):
+            if i & 1:
+                n = g.add({"Mix": "Multiply" if (i >> 1) & 1 else "Add"})
+                g.connect(prev, n, 0, 0)
+                g.connect(b, n, 0, 1)
+            else:
+                n = g.add({"Mix": "Subtract"})
+                g.connect(white, n, 0, 0)
+                g.connect(prev, n, 0, 1)
+            prev = n
+        lasts.append(prev)
+    while len(lasts) > 1:
+        nxt = []
+        for i in range(0, len(lasts) - 1, 2):
+            n = g.add({"Mix": "Add"})
+            g.connect(lasts[i], n, 0, 0)
+            g.connect(lasts[i + 1], n, 0, 1)
+            nxt.append(n)
+        if len(lasts) & 1:
+            nxt.append(lasts[-1])
+        lasts = nxt
+    return g.dict(), lasts[0]
+
+
+def embedded_images(orc, graph):
+    ids = sorted(n["node_type"]["Embed"] for n in graph["nodes"] if isinstance(n["node_type"], dict) and "Embed" in n["node_type"])
+    return {i: orc.Image([splitmix_plane(0x5EED0100 + i, c, H, W) for c in range(4)]) for i in ids}
+
+
+class HostOnlyTexPro:
+    def __init__(self):
+        import ctypes as C
+        from kanter_core_amd import _lib
+        self._h = C.c_void_p()
+        assert _lib.load().kc_tex_pro_new(10_000_000, C.byref(self._h)) == 0
+
+    def new_live_graph(self):
+        import ctypes as C
+        from kanter_core_amd import _lib
+        h = C.c_void_p()
+        assert _lib.load().kc_tex_pro_new_live_graph(self._h, C.byref(h)) == 0
+        return kc.LiveGraph(h.value, self)
+
+
+def host_live_graph(graph):
+    lg = HostOnlyTexPro().new_live_graph()
+    lg.set_node_graph(kc.NodeGraph.from_json(json.dumps(graph)))
+    return lg
+
+
+# ------------------------------------------------------------------------------------------ plan properties
+def check_plan(graph, root, plan, world):
+    nodes = {n: (r, c, k) for (n, r, c, k) in plan.nodes}
+    kinds = {n["node_id"]: n["node_type"] for n in graph["nodes"]}
+    assert root in nodes and plan.world == world and plan.home == 0
+    # topological: every parent of a listed node that is itself listed comes earlier
+    order = [n for (n, _, _, _) in plan.nodes]
+    for e in graph["edges"]:
+        if e["input_id"] in nodes:
+            assert e["output_id"] in nodes and order.index(e["output_id"]) < order.index(e["input_id"])
+    for n, (r, c, k) in nodes.items():
+        t = kinds[n]
+        is_src = isinstance(t, dict) and ("Embed" in t or "Image" in t)
+        assert (k == kc.NodeKind.Source) == is_src
+        assert (r == -1) == (k == kc.NodeKind.Replicated) and -1 <= r < world
+        if isinstance(t, dict) and "Value" in t:
+            assert k == kc.NodeKind.Replicated
+    # transfers == exactly the edges from a placed producer to a compute consumer on another rank
+    want = set()
+    for e in graph["edges"]:
+        if e["input_id"] in nodes and nodes[e["input_id"]][2] == kc.NodeKind.Compute:
+            pr, cr = nodes[e["output_id"]][0], nodes[e["input_id"]][0]
+            if pr != -1 and pr != cr:
+                want.add((e["output_id"], e["output_slot"], pr, cr))
+    got = [(n, s, a, b) for (n, s, a, b, _) in plan.transfers]
+    assert len(got) == len(set(got)) and set(got) == want
+    # execution order: a transfer's producer never depends on a later transfer's data arriving at its rank
+    levels = [lv for (_, _, _, _, lv) in plan.transfers]
+    assert levels == sorted(levels) and plan.levels == (max(levels) + 1 if levels else 1)
+    return nodes
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_partition_plan_of_diamond_fanin_broadcast_graph(world):
+    graph, root, nm = diamond_fanin_broadcast_graph()
+    lg = host_live_graph(graph)
+    plan = lg.partition(root, world, kc.PartitionPolicy.Spread)
+    nodes = check_plan(graph, root, plan, world)
+    rank = lambda name: nodes[nm[name]][0]  # noqa: E731
+    # chains stay together, the join region sits on the home rank, constants are replicated
+    assert rank("a1") == rank("a2") and rank("c1") == rank("sep") == rank("c2")
+    assert rank("j1") == rank("j2") == rank("out") == plan.home
+    assert rank("one") == rank("white") == -1
+    if world == 1:
+        assert plan.transfers == []
+    else:
+        used = {rank(x) for x in ("a1", "p1", "b1", "c1")}
+        assert len(used) == min(world, 3) or len(used) == min(world, 4)  # the four branch components fill the ranks
+        # p1 feeds b1 and c1: whenever those sit on ranks other than p1's, p1's slot is listed once per destination
+        dsts = sorted(d for (n, s, a, d, _) in plan.transfers if n == nm["p1"])
+        assert dsts == sorted({rank("b1"), rank("c1")} - {rank("p1")})
+    # the plan is a pure function of the graph: a second live graph gives the same answer
+    again = host_live_graph(graph).partition(root, world, kc.PartitionPolicy.Spread)
+    assert again.nodes == plan.nodes and again.transfers == plan.transfers
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_partition_plan_of_fanin_graph_is_a_gather(world):
+    graph, root = fanin_graph(8, 4)
+    lg = host_live_graph(graph)
+    plan = lg.partition(root, world, kc.PartitionPolicy.Spread)
+    nodes = check_plan(graph, root, plan, world)
+    # 8 branches over `world` ranks, evenly; every transfer is a branch result going straight to the home rank
+    per_rank = {}
+    for (n, r, c, k) in plan.nodes:
+        if k == kc.NodeKind.Compute:
+            per_rank.setdefault(r, set()).add(c)
+    branch_comps = {r: len(cs) for r, cs in per_rank.items()}
+    assert sorted(branch_comps) == list(range(world))
+    assert all(d == plan.home and lv == 0 for (_, _, _, d, lv) in plan.transfers)
+    assert len(plan.transfers) == 8 - 8 // world
+    # charging the transfers (Auto) keeps a graph this small on one GPU
+    auto = lg.partition(root, world, kc.PartitionPolicy.Auto)
+    assert auto.transfers == [] and {r for (_, r, _, k) in auto.nodes if k != kc.NodeKind.Replicated} == {0}
+    assert nodes[root][0] == plan.home
+
+
+def test_partition_rejects_cycles_and_bad_arguments():
+    g = G()
+    a, b = g.add({"Mix": "Add"}), g.add({"Mix": "Add"})
+    g.connect(a, b, 0, 0)
+    g.connect(b, a, 0, 0)
+    lg = host_live_graph(g.dict())
+    with pytest.raises(kc.TexProError):
+        lg.partition(b, 2)
+    graph, root = fanin_graph(2, 2)
+    lg = host_live_graph(graph)
+    for bad in (0, -1, 5000):
+        with pytest.raises(kc.TexProError):
+            lg.partition(root, bad)
+    with pytest.raises(kc.TexProError):
+        lg.partition(123456, 2)
+
+
+# ------------------------------------------------------------------------------------------ exchange, for real
+class OracleBackend:
+    """Slot store for PartitionedEvaluator on the CPU: oracle.RefGraph evaluates the local nodes, torch CPU tensors
+    carry the planes.  Only the embedded images of sources the plan places on this rank exist here."""
+
+    def __init__(self, orc, graph, embedded, plan, rank):
+        mine = {n for (n, r, _, k) in plan.nodes if r == rank and k == kc.NodeKind.Source}
+        local = {}
+        for n in graph["nodes"]:
+            t = n["node_type"]
+            if isinstance(t, dict) and "Embed" in t and n["node_id"] in mine:
+                local[t["Embed"]] = embedded[t["Embed"]]
+        self.orc, self.ref = orc, orc.RefGraph(graph, embedded=local)
+        self.allowed = {n for (n, r, _, _) in plan.nodes if r in (rank, -1)}
+        self.evaluated = []
+
+    def evaluate(self, node_id):
+        assert node_id in self.allowed, "rank evaluates a node that is not placed on it: %d" % node_id
+        self.evaluated.append(node_id)
+        self.ref.node_slot_datas(node_id)
+
+    def export_slot(self, node_id, slot_id):
+        img = self.ref.slot_data(node_id, slot_id).image
+        h, w = img.planes[0].shape
+        tensors = [torch.from_numpy(np.ascontiguousarray(p)) for p in img.planes]
+        return {"w": w, "h": h, "planes": [("m", i) for i in range(len(tensors))]}, tensors, img
+
+    def alloc_slot(self, header):
+        n = len(header["planes"])
+        tensors = [torch.empty(header["h"], header["w"], dtype=torch.float32) for _ in range(n)]
+        return tensors, tensors
+
+    def import_slot(self, node_id, slot_id, header, tensors):
+        img = self.orc.Image([t.numpy() for t in tensors])
+        self.ref.results.setdefault(node_id, [])
+        self.ref.results[node_id] = [s for s in self.ref.results[node_id] if s.slot_id != slot_id] + [self.orc.SlotData(node_id, slot_id, img)]
+
+    def result(self, node_id, slot_id=0):
+        return self.ref.slot_data(node_id, slot_id).image
 
 
 def _free_port():
@@ -55,44 +284,56 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n_branches, q):
+def _worker(rank, world, port, which, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        mine = assign_branches(n_branches, world)[rank]
-        # each branch's "result" = 3 planes whose values identify (branch, plane)
-        results = [[torch.full((4, 6), float(100 * b + c)) for c in range(3)] for b in mine]
-        # ranks may own different numbers of branches: pad to the max so every rank joins every gather
-        most = max(len(x) for x in assign_branches(n_branches, world))
-        gathered_branches = []
-        for slot in range(most):
-            planes = results[slot] if slot < len(mine) else [torch.zeros(4, 6) for _ in range(3)]
-            got = gather_planes(planes, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    owned = assign_branches(n_branches, world)[r]
-                    if slot < len(owned):
-                        gathered_branches.append((owned[slot], got[r]))
-        if rank == 0:
-            gathered_branches.sort(key=lambda t: t[0])
-            total = fan_in([p for _, p in gathered_branches], lambda a, b: [x + y for x, y in zip(a, b)])
-            q.put([float(t[0, 0]) for t in total])
+        from oracle import oracle as orc
+        graph, root = (diamond_fanin_broadcast_graph()[:2] if which == "diamond" else fanin_graph(8, 4))
+        lg = host_live_graph(graph)
+        ev = PartitionedEvaluator(lg, root, policy=kc.PartitionPolicy.Spread,
+                                  backend=lambda plan, r: OracleBackend(orc, graph, embedded_images(orc, graph), plan, r))
+        for rep in range(2):  # twice: the second round must not depend on state left by the first
+            ev.backend.ref.results.clear()
+            img = ev.evaluate()
+            assert (img is not None) == (rank == ev.plan.home)
+        q.put((rank, [p.tobytes() for p in img.planes] if img is not None else None, ev.stats, ev.plan.transfers,
+               sorted(set(ev.backend.evaluated))))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_branches", [(2, 8), (3, 8), (2, 3)])
-def test_gather_and_fan_in_gloo(world, n_branches):
+@pytest.mark.parametrize("world,which", [(2, "diamond"), (3, "diamond"), (2, "fanin"), (3, "fanin")])
+def test_partitioned_evaluation_over_gloo_equals_single_process(world, which):
+    from oracle import oracle as orc
+    graph, root = (diamond_fanin_broadcast_graph()[:2] if which == "diamond" else fanin_graph(8, 4))
+    want = orc.RefGraph(graph, embedded=embedded_images(orc, graph)).slot_data(root, 0).image.planes
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_branches, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, which, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    outs = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert out == [float(sum(100 * b + c for b in range(n_branches))) for c in range(3)]
+    transfers = outs[0][3]
+    assert all(o[3] == transfers for o in outs), "ranks disagree on the plan"
+    got = outs[0][1]
+    assert got is not None and all(o[1] is None for o in outs[1:])
+    assert [g == w.tobytes() for g, w in zip(got, want)] == [True] * len(want)
+    # every listed transfer happened, nothing else moved
+    slots = {}
+    for (n, s, src, dst, _) in transfers:
+        slots.setdefault((n, s, src), []).append(dst)
+    planes = 4  # every slot here is RGBA or gray; count by what the producers report
+    sent = sum(o[2]["planes_sent"] for o in outs)
+    recv = sum(o[2]["planes_received"] for o in outs)
+    assert sent == recv and sent >= len(transfers) and sent <= planes * len(transfers)
+    # and each rank evaluated only transfer producers placed on it (+ the root on the home rank)
+    for rank, _, _, _, evaluated in outs:
+        for n in evaluated:
+            assert n == root or any(t[0] == n and t[2] == rank for t in transfers)
