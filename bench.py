@@ -118,10 +118,13 @@ def main():
     # each returns: step(), node_px per step (this rank), algorithmic HBM bytes per step, description
     host_a = host_b = None
     rows = S
+    band = None
     if args.workload == "chain32_rows":
-        # strong scaling of ONE graph: this rank owns a row band of every plane
+        # strong scaling of ONE graph: this rank evaluates rows [y0, y1) of the result through the library's row-band
+        # path (kc_live_graph_evaluate_band, csrc/bands.cpp) and holds only those rows of the inputs
         y0, y1 = multi_gpu.row_bands(S, world)[rank]
         rows = y1 - y0
+        band = (y0, y1)
         full = lambda seed: [splitmix_plane(seed, c, S, S)[y0:y1].copy() for c in range(4)]  # noqa: E731
         host_a, host_b = full(SEED_A), full(SEED_B)
         args.workload = "chain32"
@@ -136,14 +139,23 @@ def main():
         def make(use_cache):
             lg = tp.new_live_graph()
             lg.use_cache = use_cache
-            na, nb = embed(kc, lg, img_a, 0), embed(kc, lg, img_b, 1)
+            if band is None:
+                na, nb = embed(kc, lg, img_a, 0), embed(kc, lg, img_b, 1)
+            else:
+                lg.embed_slot_data_band(kc.SlotData(0, 0, img_a), 0, band[0], S)
+                lg.embed_slot_data_band(kc.SlotData(0, 0, img_b), 1, band[0], S)
+                na, nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(0))), lg.add_node(kc.Node.new(kc.NodeType.Embed(1)))
             first, last = add_chain(kc, lg, na, nb, N)
             return lg, na, first, last
 
         g = make(False)
+        band_keep = []
 
         def step(gg=g):
             lg, na, first, last = gg
+            if band is not None:
+                band_keep[:] = [lg.evaluate_band(last, band[0], band[1])]  # stateless: every call evaluates the band
+                return
             lg.connect(na, first, 0, 0)  # re-plugging the input dirties the whole chain (live_graph.rs:488-511)
             lg.await_clean(last)
 
@@ -362,7 +374,7 @@ def main():
         },
     }
 
-    if rank == 0 and args.workload == "chain32" and not args.no_extras:
+    if rank == 0 and args.workload == "chain32" and not args.no_extras and band is None:
         # ---- the same graph with every node materialised (use_cache = true): N launches per step ----
         gu = make(True)
         k2 = max(5, args.steps // 10)
@@ -387,7 +399,7 @@ def main():
                                  "note": "8 pageable host planes uploaded, 4 downloaded, graph built and evaluated once"}
         del res, lgp
 
-    if rank == 0 and world == 1 and args.workload == "chain32" and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and args.workload == "chain32" and not args.no_cpu_baseline and band is None:
         from oracle import oracle as orc
         orc.set_threads(1)
         reps, cpu_s, ref = 0, 0.0, None

@@ -334,6 +334,24 @@ KC_API int kc_partition_transfers(const kc_partition *p, kc_transfer *out, uint3
  * the result of a finished node (src/engine.rs:34-57): the receiving side of a transfer. */
 KC_API int kc_live_graph_import_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image *image);
 
+/* Row bands: rows [y0, y1) of a node's result without computing the rest -- the data-level way to put several GPUs on one
+ * graph.  Every pixel goes through the same operations as in the whole-image evaluation (process_node, src/node/
+ * node_type.rs:213-248), so the bands of all ranks, stacked, equal it bit for bit.  Pointwise nodes need the same rows
+ * of their inputs; HeightToNormal one more row on top (toroidal: the band that starts at row 0 needs the LAST row,
+ * src/node/process_shared.rs:31-65); an implicit resize the rows its vertical taps read (src/shared.rs:159-199).  The
+ * evaluation widens every intermediate band by those halo rows and computes them redundantly: no exchange between ranks.
+ * Graph and Write nodes are not supported here.
+ *   kc_live_graph_evaluate_band: `*out` (+1 ref) is an image of (y1 - y0) rows, resident on return.
+ *   kc_live_graph_band_source_rows: which rows of every SOURCE (Embed / Image / Input*) that evaluation reads, so that
+ *     sources which are themselves sharded by rows can be loaded with exactly their halo.  y0 may be negative: row -1 is
+ *     the image's last row (the wrap).  Host only, no device needed.
+ *   kc_live_graph_embed_slot_data_band: like kc_live_graph_embed_slot_data_with_id, but `image` holds only logical rows
+ *     band_y0 .. band_y0 + rows - 1 of an image `full_height` rows high (band_y0 < 0: the wrapped rows come first). */
+typedef struct kc_band_rows { uint32_t node_id; int32_t y0, y1; uint32_t width, height; } kc_band_rows;
+KC_API int kc_live_graph_evaluate_band(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, int32_t y0, int32_t y1, kc_image **out);
+KC_API int kc_live_graph_band_source_rows(kc_live_graph *lg, uint32_t node_id, int32_t y0, int32_t y1, kc_band_rows *rows, uint32_t cap, uint32_t *count);
+KC_API int kc_live_graph_embed_slot_data_band(kc_live_graph *lg, kc_image *image, uint32_t slot_id, uint32_t embed_id, int32_t band_y0, uint32_t full_height);
+
 #ifdef __cplusplus
 }
 #endif

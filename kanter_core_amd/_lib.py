@@ -39,6 +39,10 @@ class kc_transfer(C.Structure):
                 ("level", C.c_int32)]
 
 
+class kc_band_rows(C.Structure):
+    _fields_ = [("node_id", C.c_uint32), ("y0", C.c_int32), ("y1", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 # name -> (restype, argtypes); every symbol include/kanter_core_amd.h declares.
 SIGNATURES = {
     "kc_init": (C.c_int, [C.c_int]),
@@ -65,6 +69,9 @@ SIGNATURES = {
     "kc_partition_nodes": (C.c_int, [c_vp, C.POINTER(kc_placement), C.c_uint32, c_u32p]),
     "kc_partition_transfers": (C.c_int, [c_vp, C.POINTER(kc_transfer), C.c_uint32, c_u32p]),
     "kc_live_graph_import_slot_data": (C.c_int, [c_vp, C.c_uint32, C.c_uint32, c_vp]),
+    "kc_live_graph_evaluate_band": (C.c_int, [c_vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(c_vp)]),
+    "kc_live_graph_band_source_rows": (C.c_int, [c_vp, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(kc_band_rows), C.c_uint32, c_u32p]),
+    "kc_live_graph_embed_slot_data_band": (C.c_int, [c_vp, c_vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32]),
     "kc_plane_alloc": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(c_vp)]),
     "kc_plane_const": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(c_vp)]),
     "kc_plane_wrap": (C.c_int, [c_vp, C.c_uint32, C.c_uint32, C.c_size_t, C.POINTER(c_vp)]),

@@ -831,6 +831,28 @@ class LiveGraph:
         _check(_lib.load().kc_live_graph_partition(self._h, int(root_node_id), int(world_size), int(policy), C.byref(h)))
         return Partition(h.value)
 
+    def evaluate_band(self, node_id, y0, y1, slot_id=0):
+        """Rows [y0, y1) of the node's result (an image of y1 - y0 rows), bit-identical to those rows of the whole-image
+        evaluation; intermediate bands carry the halo rows resize / HeightToNormal nodes need (csrc/bands.cpp)."""
+        out = C.c_void_p()
+        _check(_lib.load().kc_live_graph_evaluate_band(self._h, int(node_id), int(slot_id), int(y0), int(y1), C.byref(out)))
+        return SlotImage(out.value)
+
+    def band_source_rows(self, node_id, y0, y1):
+        """{source node id: (y0, y1, width, height)}: the rows of every source image that band reads (y0 < 0: wrapped)."""
+        from ._lib import kc_band_rows
+        n = C.c_uint32()
+        _check(_lib.load().kc_live_graph_band_source_rows(self._h, int(node_id), int(y0), int(y1), None, 0, C.byref(n)))
+        buf = (kc_band_rows * max(n.value, 1))()
+        _check(_lib.load().kc_live_graph_band_source_rows(self._h, int(node_id), int(y0), int(y1), buf, n.value, C.byref(n)))
+        return {buf[i].node_id: (buf[i].y0, buf[i].y1, buf[i].width, buf[i].height) for i in range(n.value)}
+
+    def embed_slot_data_band(self, slot_data, embedded_id, band_y0, full_height):
+        """Embeds an image that holds only rows band_y0 .. of a `full_height`-row image (row-band evaluation)."""
+        _check(_lib.load().kc_live_graph_embed_slot_data_band(self._h, slot_data.image._h, slot_data.slot_id, int(embedded_id),
+                                                              int(band_y0), int(full_height)))
+        return EmbeddedSlotDataId(embedded_id)
+
     def import_slot_data(self, node_id, slot_id, image):
         """The receiving side of a transfer: `image` becomes slot `slot_id` of `node_id`, which is Clean afterwards."""
         _check(_lib.load().kc_live_graph_import_slot_data(self._h, int(node_id), int(slot_id), image._h))

@@ -102,6 +102,8 @@ try {
     pool_trim();
     for (auto &kv : c.taps) (void)hipFree(kv.second.dev_block);
     c.taps.clear();
+    for (auto &kv : c.band_taps) (void)hipFree(kv.second.dev_block);
+    c.band_taps.clear();
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c.own_stream = c.stream = nullptr;
     c.inited = false;
@@ -1108,6 +1110,44 @@ try {
         if (e.slot_data_id == embed_id) return KC_ERR_INVALID_SLOT_ID;  // :329-340
     image_retain(image);
     lg->embedded.push_back(EmbeddedSlotData{ embed_id, slot_id, image });
+    return KC_OK;
+}
+KC_CATCH
+
+// ---------------------------------------------------------------- row bands (bands.cpp)
+int kc_live_graph_embed_slot_data_band(kc_live_graph *lg, kc_image *image, uint32_t slot_id, uint32_t embed_id, int32_t band_y0,
+                                       uint32_t full_height)
+try {
+    LG_LOCK(lg);
+    KC_ARG(image && full_height > 0);
+    for (auto &e : lg->embedded)
+        if (e.slot_data_id == embed_id) return KC_ERR_INVALID_SLOT_ID;
+    image_retain(image);
+    EmbeddedSlotData e{ embed_id, slot_id, image };
+    e.band_y0 = band_y0;
+    e.full_h = full_height;
+    lg->embedded.push_back(e);
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_live_graph_evaluate_band(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, int32_t y0, int32_t y1, kc_image **out)
+try {
+    LG_LOCK(lg);
+    KC_ARG(out);
+    return band_evaluate(*lg, node_id, slot_id, y0, y1, out);
+}
+KC_CATCH
+
+int kc_live_graph_band_source_rows(kc_live_graph *lg, uint32_t node_id, int32_t y0, int32_t y1, kc_band_rows *rows, uint32_t cap,
+                                   uint32_t *count)
+try {
+    LG_LOCK(lg);
+    KC_ARG(count);
+    std::vector<kc_band_rows> v;
+    KC_TRY(band_source_rows(*lg, node_id, y0, y1, v));
+    *count = (uint32_t)v.size();
+    for (uint32_t i = 0; rows && i < cap && i < *count; ++i) rows[i] = v[i];
     return KC_OK;
 }
 KC_CATCH

@@ -65,8 +65,8 @@ hipError_t launch_resize_lds(const ResizePlanes &p, int batch, uint32_t dw, uint
 // Fused resample + chain: input slot n_in - 1 of the program is produced by the resampler.
 hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);
-hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, float *nx, float *ny,
-                                   float *nz, uint32_t opitch, hipStream_t s);
+hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, uint32_t full_h, int band,
+                                   float *nx, float *ny, float *nz, uint32_t opitch, hipStream_t s);
 hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,
                         uint8_t *dst, hipStream_t s);
 hipError_t launch_from_u8(const uint8_t *src, int channels, uint32_t w, uint32_t h, float *const planes[4],

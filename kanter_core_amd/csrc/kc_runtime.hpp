@@ -33,6 +33,7 @@ struct kc_plane {
     float cval = 0.0f;
     kc::ChainLink *link = nullptr;  // LAZY: the last step and what it continues (see ChainLink)
     kc::Chain *chain = nullptr;     // LAZY: the flattened program, built when the plane is forced
+    kc_plane *view_of = nullptr;  // MEM, not owned: rows of this (retained) plane, see bands.cpp
     kc_plane *rz_src = nullptr;  // retained; MEM
     int rz_filter = 0;
 };
@@ -112,6 +113,7 @@ struct Context {
     uint64_t bytes_in_use = 0, bytes_cached = 0, launches = 0;
     uint64_t alg_bytes = 0;  // algorithmic HBM bytes of every kernel launched so far (DESIGN.md section 3's per-kernel figures)
     std::map<std::tuple<uint32_t, uint32_t, int>, TapsEntry> taps;
+    std::map<std::tuple<uint32_t, uint32_t, int, int32_t, int32_t, int32_t>, TapsEntry> band_taps;  // row-band vertical tables
     // Within one graph evaluation the same plane resized to the same size with the same filter is
     // computed once (the reference resamples it per consuming node, src/shared.rs:152-207; planes
     // are immutable, so the result is identical).  Both planes are retained while memoised.
@@ -175,11 +177,14 @@ int separate_process(kc_image *in, kc_image *out[4]);
 int combine_process(kc_image *const in[4], kc_image **out);
 int value_process(float v, kc_image **out);
 int height_to_normal_process(kc_image *in, kc_image **out);
+int height_to_normal_band(kc_image *in_with_halo, uint32_t full_h, kc_image **out);  // rows + 1 input rows, halo first
 
 // ---- resize (resize.cpp) ----
 int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t);
 int resize_image(kc_image *src, kc_size size, int filter, kc_image **out);
 int resize_force(kc_plane *p);  // RESIZE -> MEM through the plain resize kernel
+int resize_planes_band(kc_plane *const *srcs, int n, int32_t src_y0, uint32_t src_h_full, kc_size dst_full, int32_t a, int32_t b,
+                       int filter, kc_plane **outs);
 int resize_force_many(kc_plane *const *planes, int n);  // same; equal resamples share launches
 // Runs a chain whose operands include ONE resampled plane per channel inside the resize kernel
 // (phase 2 feeds the chain program).  *launched = false when the case is not eligible (taps not
@@ -295,6 +300,9 @@ struct SlotData {
 struct EmbeddedSlotData {
     uint32_t slot_data_id, slot_id;
     kc_image *image;
+    // row-band evaluation only (bands.cpp): full_h != 0 => `image` holds logical rows band_y0 .. of a full_h-row image
+    int32_t band_y0 = 0;
+    uint32_t full_h = 0;
 };
 
 }  // namespace kc
@@ -346,6 +354,9 @@ struct kc_partition {
 };
 
 namespace kc {
+// Row-band evaluation (bands.cpp)
+int band_evaluate(kc_live_graph &lg, uint32_t root, uint32_t slot, int32_t y0, int32_t y1, kc_image **out);
+int band_source_rows(kc_live_graph &lg, uint32_t root, int32_t y0, int32_t y1, std::vector<kc_band_rows> &out);
 int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out);
 // process_node, src/node/node_type.rs:213-248: inputs in edge insertion order.
 int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData> &inputs,

@@ -914,20 +914,26 @@ static __device__ __forceinline__ void h2n_px(float px, float up, float left, fl
     b = nz * 0.5f + 0.5f;
 }
 
+// BAND = false: the whole plane, rows wrap around (row -1 = row h - 1).  BAND = true: a row band -- `hgt` holds
+// h + 1 rows, the band's rows preceded by the row above its first one (the caller's halo: the previous band's last
+// row, or the image's last row for the band that starts at row 0); `full_h` is the height of the whole image, which
+// is what the bitangent's 1 / height means (src/node/height_to_normal.rs:38).
+template <bool BAND>
 __global__ __launch_bounds__(256) void height_to_normal_kernel(const float *__restrict__ hgt, uint32_t hpitch,
-                                                               uint32_t w, uint32_t h, float *__restrict__ nx,
-                                                               float *__restrict__ ny, float *__restrict__ nz,
-                                                               uint32_t opitch)
+                                                               uint32_t w, uint32_t h, uint32_t full_h,
+                                                               float *__restrict__ nx, float *__restrict__ ny,
+                                                               float *__restrict__ nz, uint32_t opitch)
 {
     const uint32_t row_units = (w + 3) / 4;
     const uint32_t total = row_units * h;
     const float pdx = 1.0f / (float)w;
-    const float pdy = 1.0f / (float)h;
+    const float pdy = 1.0f / (float)full_h;
     for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const uint32_t y = idx / row_units;
         const uint32_t q = idx - y * row_units;
-        const uint32_t yu = y == 0 ? h - 1 : y - 1;
-        const float *rowp = hgt + (size_t)y * hpitch;
+        const uint32_t yc = BAND ? y + 1 : y;                          // row of this pixel in `hgt`
+        const uint32_t yu = BAND ? y : (y == 0 ? h - 1 : y - 1);       // row above it
+        const float *rowp = hgt + (size_t)yc * hpitch;
         const float4 cur = *reinterpret_cast<const float4 *>(rowp + 4 * q);
         const float4 upv = *reinterpret_cast<const float4 *>(hgt + (size_t)yu * hpitch + 4 * q);
         const float lft = q == 0 ? rowp[w - 1] : rowp[4 * q - 1];
@@ -943,14 +949,18 @@ __global__ __launch_bounds__(256) void height_to_normal_kernel(const float *__re
     }
 }
 
-hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, float *nx, float *ny,
-                                   float *nz, uint32_t opitch, hipStream_t s)
+// h = rows to produce; band != 0: `hgt` has h + 1 rows (halo row first) and full_h is the whole image's height.
+hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, uint32_t full_h, int band,
+                                   float *nx, float *ny, float *nz, uint32_t opitch, hipStream_t s)
 {
     const uint64_t total = (uint64_t)((w + 3) / 4) * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    height_to_normal_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, nx, ny, nz, opitch);
+    if (band)
+        height_to_normal_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch);
+    else
+        height_to_normal_kernel<false><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, h, nx, ny, nz, opitch);
     return hipGetLastError();
 }
 

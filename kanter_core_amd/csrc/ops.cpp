@@ -302,8 +302,9 @@ int value_process(float v, kc_image **out)
     return KC_OK;
 }
 
-// height_to_normal::process, src/node/height_to_normal.rs:16-77.
-int height_to_normal_process(kc_image *in, kc_image **out)
+// height_to_normal::process, src/node/height_to_normal.rs:16-77.  full_h == 0: the whole image.  full_h > 0: `in` is a
+// row band preceded by its halo row (rows + 1 rows) of an image full_h rows high; the result has `rows` rows.
+static int height_to_normal_impl(kc_image *in, uint32_t full_h, kc_image **out)
 {
     *out = nullptr;
     if (!in || in->is_rgba()) return KC_OK;  // reference returns an empty Vec
@@ -312,13 +313,18 @@ int height_to_normal_process(kc_image *in, kc_image **out)
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     kc_plane *src = in->planes[0];
     KC_TRY(plane_materialize(src));
-    const uint32_t w = src->w, h = src->h;
+    const bool band = full_h != 0;
+    if (band && src->h < 2) {
+        set_error("height_to_normal band: the input must hold the halo row and at least one row");
+        return KC_ERR_INVALID_ARG;
+    }
+    const uint32_t w = src->w, h = band ? src->h - 1 : src->h;
     kc_plane *p[4] = { nullptr, nullptr, nullptr, nullptr };
     int s = KC_OK;
     for (int i = 0; i < 3 && s == KC_OK; ++i) s = plane_new_mem(w, h, &p[i]);
     if (s == KC_OK) {
-        hipError_t e = launch_height_to_normal(src->dptr, (uint32_t)(src->pitch / 4), w, h, p[0]->dptr, p[1]->dptr,
-                                               p[2]->dptr, (uint32_t)(p[0]->pitch / 4), c.stream);
+        hipError_t e = launch_height_to_normal(src->dptr, (uint32_t)(src->pitch / 4), w, h, band ? full_h : h, band ? 1 : 0,
+                                               p[0]->dptr, p[1]->dptr, p[2]->dptr, (uint32_t)(p[0]->pitch / 4), c.stream);
         if (e != hipSuccess) s = hip_fail(e, "launch_height_to_normal");
         else {
             c.launches++;
@@ -331,6 +337,17 @@ int height_to_normal_process(kc_image *in, kc_image **out)
     }
     for (int i = 0; i < 4; ++i) plane_release(p[i]);
     return s;
+}
+
+int height_to_normal_process(kc_image *in, kc_image **out) { return height_to_normal_impl(in, 0, out); }
+
+int height_to_normal_band(kc_image *in_with_halo, uint32_t full_h, kc_image **out)
+{
+    if (full_h == 0) {
+        set_error("height_to_normal band: full height must be given");
+        return KC_ERR_INVALID_ARG;
+    }
+    return height_to_normal_impl(in_with_halo, full_h, out);
 }
 
 }  // namespace kc

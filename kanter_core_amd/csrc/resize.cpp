@@ -99,18 +99,11 @@ int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
     return KC_OK;
 }
 
-static int get_taps(uint32_t in_n, uint32_t out_n, int filter, TapsEntry **out)
+// Copies e.host into one device block and points e.dev at it.
+static int taps_upload(TapsEntry &e)
 {
     Context &c = ctx();
-    auto key = std::make_tuple(in_n, out_n, filter);
-    auto it = c.taps.find(key);
-    if (it != c.taps.end()) {
-        *out = &it->second;
-        return KC_OK;
-    }
-    TapsEntry e;
-    KC_TRY(build_taps_host(in_n, out_n, filter, e.host));
-    const size_t nl = (size_t)out_n * sizeof(uint32_t);
+    const size_t nl = e.host.left.size() * sizeof(uint32_t);
     const size_t nw = e.host.w.size() * sizeof(float);
     const size_t nl_pad = (nl + 255) / 256 * 256;
     e.dev_bytes = 2 * nl_pad + (nw + 32 + 255) / 256 * 256;  // + 32: register-tap loads past the last row
@@ -122,13 +115,77 @@ static int get_taps(uint32_t in_n, uint32_t out_n, int filter, TapsEntry **out)
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
     if (err != hipSuccess) {
         (void)hipFree(e.dev_block);
+        e.dev_block = nullptr;
         return hip_fail(err, "upload tap table");
     }
     e.dev.left = (const uint32_t *)base;
     e.dev.count = (const uint32_t *)(base + nl_pad);
     e.dev.w = (const float *)(base + 2 * nl_pad);
     e.dev.stride = e.host.stride;
+    return KC_OK;
+}
+
+static int get_taps(uint32_t in_n, uint32_t out_n, int filter, TapsEntry **out)
+{
+    Context &c = ctx();
+    auto key = std::make_tuple(in_n, out_n, filter);
+    auto it = c.taps.find(key);
+    if (it != c.taps.end()) {
+        *out = &it->second;
+        return KC_OK;
+    }
+    TapsEntry e;
+    KC_TRY(build_taps_host(in_n, out_n, filter, e.host));
+    KC_TRY(taps_upload(e));
     auto ins = c.taps.emplace(key, std::move(e));
+    *out = &ins.first->second;
+    return KC_OK;
+}
+
+// Vertical tap table of a ROW BAND: output rows a .. b-1 of the logical out_n-row image (negative rows wrap
+// around: a toroidal consumer such as HeightToNormal asks for row -1 = out_n - 1), read from a source band that
+// holds rows src_y0 .. src_y0 + src_rows - 1 of the logical in_n-row source.  The weights are the full table's
+// (same f32 values, same order): a band is computed exactly as the same rows of the whole image would be.
+static int get_band_taps(uint32_t in_n, uint32_t out_n, int filter, int32_t a, int32_t b, int32_t src_y0, uint32_t src_rows,
+                         TapsEntry **out)
+{
+    Context &c = ctx();
+    auto key = std::make_tuple(in_n, out_n, filter, a, b, src_y0);
+    auto it = c.band_taps.find(key);
+    if (it != c.band_taps.end()) {
+        *out = &it->second;
+        return KC_OK;
+    }
+    TapsEntry *full = nullptr;
+    KC_TRY(get_taps(in_n, out_n, filter, &full));
+    TapsEntry e;
+    const uint32_t rows = (uint32_t)(b - a), stride = full->host.stride;
+    e.host.stride = stride;
+    e.host.left.resize(rows);
+    e.host.count.resize(rows);
+    e.host.w.assign((size_t)rows * stride, 0.0f);
+    e.host.min_count = stride;
+    for (uint32_t i = 0; i < rows; ++i) {
+        const int64_t logical = (int64_t)a + i;
+        const uint32_t oy = (uint32_t)(((logical % (int64_t)out_n) + out_n) % out_n);
+        const int64_t rel = (int64_t)full->host.left[oy] - src_y0;
+        const uint32_t n = full->host.count[oy];
+        if (rel < 0 || rel + n > src_rows) {
+            set_error("resize band: the source band does not hold the rows this output band needs (halo rows missing)");
+            return KC_ERR_INVALID_ARG;
+        }
+        e.host.left[i] = (uint32_t)rel;
+        e.host.count[i] = n;
+        if (n < e.host.min_count) e.host.min_count = n;
+        std::copy(full->host.w.begin() + (size_t)oy * stride, full->host.w.begin() + (size_t)(oy + 1) * stride,
+                  e.host.w.begin() + (size_t)i * stride);
+    }
+    KC_TRY(taps_upload(e));
+    if (c.band_taps.size() >= 64) {  // bands come in a handful of shapes per graph; bound what a long-lived process keeps
+        for (auto &kv : c.band_taps) (void)hipFree(kv.second.dev_block);
+        c.band_taps.clear();
+    }
+    auto ins = c.band_taps.emplace(key, std::move(e));
     *out = &ins.first->second;
     return KC_OK;
 }
@@ -238,16 +295,13 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
     return t;
 }
 
-// Runs the resample srcs[i] -> dsts[i] (all resident; equal source sizes, equal target sizes): one
-// launch for the whole batch in the tiled form, two per plane in the two-pass form.
-static int resize_run(kc_plane *const *srcs, kc_plane *const *dsts, int n, int filter)
+// Runs the resample srcs[i] -> dsts[i] (all resident; equal source sizes, equal target sizes) with the given tap
+// tables: one launch for the whole batch in the tiled form, two per plane in the two-pass form.
+static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, TapsEntry *tv, TapsEntry *th)
 {
     Context &c = ctx();
     const kc_plane *s0 = srcs[0];
     const kc_size size{ dsts[0]->w, dsts[0]->h };
-    TapsEntry *tv = nullptr, *th = nullptr;
-    KC_TRY(get_taps(s0->h, size.height, filter, &tv));
-    KC_TRY(get_taps(s0->w, size.width, filter, &th));
     // Tiled single pass when a tile's vertical-pass intermediate and tap tables fit in LDS; very wide
     // windows fall back to two passes through an HBM intermediate (KC_RESIZE_MODE=3 forces them).
     if (c.resize_mode != 3) {
@@ -283,6 +337,40 @@ static int resize_run(kc_plane *const *srcs, kc_plane *const *dsts, int n, int f
         c.alg_bytes += 4 * ((uint64_t)s0->w * s0->h + 2 * (uint64_t)s0->w * size.height + (uint64_t)size.width * size.height);
     }
     return KC_OK;
+}
+
+static int resize_run(kc_plane *const *srcs, kc_plane *const *dsts, int n, int filter)
+{
+    TapsEntry *tv = nullptr, *th = nullptr;
+    KC_TRY(get_taps(srcs[0]->h, dsts[0]->h, filter, &tv));
+    KC_TRY(get_taps(srcs[0]->w, dsts[0]->w, filter, &th));
+    return resize_run_taps(srcs, dsts, n, tv, th);
+}
+
+// Row-band form of resize_image for resident planes (bands.cpp): srcs[i] holds rows src_y0 .. of a logical
+// (srcs[i]->w x src_h_full) plane; outs[i] receives rows a .. b-1 (negative = wrapped) of its resample to dst_full.
+int resize_planes_band(kc_plane *const *srcs, int n, int32_t src_y0, uint32_t src_h_full, kc_size dst_full, int32_t a, int32_t b,
+                       int filter, kc_plane **outs)
+{
+    KC_TRY(need_init());
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    if (n < 1 || n > 4 || b <= a) {
+        set_error("resize band: bad arguments");
+        return KC_ERR_INVALID_ARG;
+    }
+    TapsEntry *tv = nullptr, *th = nullptr;
+    KC_TRY(get_band_taps(src_h_full, dst_full.height, filter, a, b, src_y0, srcs[0]->h, &tv));
+    KC_TRY(get_taps(srcs[0]->w, dst_full.width, filter, &th));
+    int s = KC_OK;
+    for (int i = 0; i < n; ++i) outs[i] = nullptr;
+    for (int i = 0; i < n && s == KC_OK; ++i) s = plane_new_mem(dst_full.width, (uint32_t)(b - a), &outs[i]);
+    if (s == KC_OK) s = resize_run_taps(srcs, outs, n, tv, th);
+    if (s != KC_OK)
+        for (int i = 0; i < n; ++i) {
+            plane_release(outs[i]);
+            outs[i] = nullptr;
+        }
+    return s;
 }
 
 // RESIZE -> MEM through the plain resize kernels.  Planes that resample equally sized sources to the

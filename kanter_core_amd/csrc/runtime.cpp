@@ -148,6 +148,7 @@ void plane_release(kc_plane *p)
         if (p->chain) delete p->chain;
         if (p->link) delete p->link;
         if (p->rz_src) plane_release(p->rz_src);
+        if (p->view_of) plane_release(p->view_of);
         if (p->owned && p->dptr) pool_free(p->dptr, p->bytes);
         delete p;
     }

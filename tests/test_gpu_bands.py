@@ -1,0 +1,179 @@
+"""Row-band evaluation on the device: the bands of a result, evaluated one after the other on one GPU (what N ranks do
+concurrently), stacked, must equal the whole-image evaluation BIT FOR BIT -- for pointwise graphs, graphs with implicit
+resizes (up- and down-sampling, five filters), HeightToNormal (1-row toroidal halo: the first band needs the last row),
+and sources that are themselves sharded by rows and embedded with exactly the halo the planner asks for."""
+import json
+
+import numpy as np
+import pytest
+
+from golden_graphs import G
+from util import SEED_A, SEED_B, assert_planes, splitmix_plane
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kc():
+    import kanter_core_amd as kc
+    kc.init(0)
+    return kc
+
+
+def build(kc, graph, images, bands=None):
+    """LiveGraph of `graph`; images: {embed id: [planes]}; bands: {embed id: (y0, y1)} embeds only those rows."""
+    tp = kc.TextureProcessor.new()
+    lg = tp.new_live_graph()
+    lg.set_node_graph(kc.NodeGraph.from_json(json.dumps(graph)))
+    for eid, planes in images.items():
+        if bands is None or eid not in bands:
+            lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(planes)), eid)
+        else:
+            y0, y1 = bands[eid]
+            h = planes[0].shape[0]
+            rows = [r % h for r in range(y0, y1)]  # y0 < 0: the wrapped rows come first
+            lg.embed_slot_data_band(kc.SlotData(0, 0, kc.SlotImage.from_planes([p[rows] for p in planes])), eid, y0, h)
+    return tp, lg
+
+
+def splits(h):
+    return [[(0, h)], [(0, h // 2), (h // 2, h)], [(0, 1), (1, h // 3), (h // 3, h - 1), (h - 1, h)],
+            [(y, min(y + 7, h)) for y in range(0, h, 7)]]
+
+
+def check_bands(kc, graph, images, root, what):
+    tp, lg = build(kc, graph, images)
+    whole = lg.await_clean(root).slot_data(root, 0).image.planes()
+    h = whole[0].shape[0]
+    for split in splits(h):
+        tp2, lg2 = build(kc, graph, images)
+        parts = [lg2.evaluate_band(root, y0, y1).planes() for (y0, y1) in split]
+        assert all(p[0].shape[0] == y1 - y0 for p, (y0, y1) in zip(parts, split))
+        stacked = [np.concatenate([p[c] for p in parts], axis=0) for c in range(len(whole))]
+        assert_planes(stacked, whole, what="%s, %d bands" % (what, len(split)))
+    return whole
+
+
+def chain_graph(n_nodes=12):
+    g = G()
+    a, b = g.add({"Embed": 0}), g.add({"Embed": 1})
+    one = g.add({"Value": 1.0})
+    white = g.add("CombineRgba")
+    for s in range(3):
+        g.connect(one, white, 0, s)
+    prev = a
+    for i in range(1, n_nodes + 1):
+        if i & 1:
+            n = g.add({"Mix": "Multiply" if (i >> 1) & 1 else "Add"})
+            g.connect(prev, n, 0, 0)
+            g.connect(b, n, 0, 1)
+        else:
+            n = g.add({"Mix": "Subtract"})
+            g.connect(white, n, 0, 0)
+            g.connect(prev, n, 0, 1)
+        prev = n
+    return g.dict(), prev
+
+
+def test_pointwise_chain_bands(kc):
+    h, w = 61, 200
+    imgs = {0: [splitmix_plane(SEED_A, c, h, w) for c in range(4)], 1: [splitmix_plane(SEED_B, c, h, w) for c in range(4)]}
+    graph, root = chain_graph()
+    check_bands(kc, graph, imgs, root, "chain")
+
+
+@pytest.mark.parametrize("filt", ["Nearest", "Triangle", "CatmullRom", "Gaussian", "Lanczos3"])
+@pytest.mark.parametrize("sizes", [((48, 64), (12, 16)), ((40, 72), (131, 200)), ((57, 33), (57, 90))])
+def test_resize_and_height_to_normal_bands(kc, filt, sizes):
+    """big + small -> Mix (the smaller / larger one is resampled to the other's size, both axes or one) -> Separate ->
+    HeightToNormal(R) -> Mix(Multiply) with the blend -> Output: resize halos and the toroidal 1-row halo together."""
+    (h0, w0), (h1, w1) = sizes
+    g = G()
+    e0, e1 = g.add({"Embed": 0}), g.add({"Embed": 1})
+    mix = g.add({"Mix": "Add"}, filt=filt)
+    g.connect(e0, mix, 0, 0)
+    g.connect(e1, mix, 0, 1)
+    sep = g.add("SeparateRgba")
+    g.connect(mix, sep, 0, 0)
+    h2n = g.add("HeightToNormal")
+    g.connect(sep, h2n, 1, 0)
+    fin = g.add({"Mix": "Multiply"}, filt=filt)
+    g.connect(h2n, fin, 0, 0)
+    g.connect(mix, fin, 0, 1)
+    out = g.add({"OutputRgba": "out"})
+    g.connect(fin, out, 0, 0)
+    imgs = {0: [splitmix_plane(SEED_A, c, h0, w0) for c in range(4)], 1: [splitmix_plane(SEED_B, c, h1, w1) for c in range(4)]}
+    check_bands(kc, g.dict(), imgs, out, "%s %s" % (filt, sizes))
+
+
+def test_two_height_to_normal_nodes_in_a_row(kc):
+    """Halo of 2: the second node's band needs one more row of the first node's output, which needs one more of its input."""
+    h, w = 37, 52
+    g = G()
+    e0 = g.add({"Embed": 0})
+    s1 = g.add("SeparateRgba")
+    g.connect(e0, s1, 0, 0)
+    n1 = g.add("HeightToNormal")
+    g.connect(s1, n1, 0, 0)
+    s2 = g.add("SeparateRgba")
+    g.connect(n1, s2, 0, 0)
+    n2 = g.add("HeightToNormal")
+    g.connect(s2, n2, 2, 0)
+    imgs = {0: [splitmix_plane(SEED_A, c, h, w) for c in range(4)]}
+    check_bands(kc, g.dict(), imgs, n2, "h2n x2")
+
+
+def test_sharded_sources_with_exactly_the_planned_halo(kc):
+    """Each 'rank' embeds only the rows kc_live_graph_band_source_rows asks for -- including the wrapped last row for the
+    band that starts at row 0 -- and still reproduces its band of the whole-image result."""
+    (h0, w0), (h1, w1) = (64, 96), (16, 24)
+    g = G()
+    e0, e1 = g.add({"Embed": 0}), g.add({"Embed": 1})
+    mix = g.add({"Mix": "Subtract"}, filt="CatmullRom")
+    g.connect(e0, mix, 0, 0)
+    g.connect(e1, mix, 0, 1)
+    sep = g.add("SeparateRgba")
+    g.connect(mix, sep, 0, 0)
+    h2n = g.add("HeightToNormal")
+    g.connect(sep, h2n, 0, 0)
+    graph = g.dict()
+    imgs = {0: [splitmix_plane(SEED_A, c, h0, w0) for c in range(4)], 1: [splitmix_plane(SEED_B, c, h1, w1) for c in range(4)]}
+    tp, lg = build(kc, graph, imgs)
+    whole = lg.await_clean(h2n).slot_data(h2n, 0).image.planes()
+    embed_of = {e0: 0, e1: 1}
+    for (y0, y1) in ((0, 16), (16, 40), (40, 64)):
+        need = lg.band_source_rows(h2n, y0, y1)
+        bands = {embed_of[n]: (a, b) for n, (a, b, _, _) in need.items()}
+        if y0 == 0:
+            assert bands[0] == (-1, 16)
+        else:
+            assert bands[0] == (y0 - 1, y1) and bands[1][1] - bands[1][0] < h1
+        tp2, lg2 = build(kc, graph, imgs, bands=bands)
+        got = lg2.evaluate_band(h2n, y0, y1).planes()
+        assert_planes(got, [p[y0:y1] for p in whole], what="sharded sources %d:%d" % (y0, y1))
+        # one row less than planned is refused, not silently wrong
+        if y0 > 0:
+            short = dict(bands)
+            short[0] = (bands[0][0] + 1, bands[0][1])
+            tp3, lg3 = build(kc, graph, imgs, bands=short)
+            with pytest.raises(kc.TexProError):
+                lg3.evaluate_band(h2n, y0, y1)
+
+
+def test_band_at_full_size_4096_with_resize_and_h2n(kc):
+    """BASELINE size: 512^2 -> 4096^2 Triangle resize feeding a blend and a HeightToNormal, two bands vs the whole image."""
+    S, s = 4096, 512
+    g = G()
+    e0, e1 = g.add({"Embed": 0}), g.add({"Embed": 1})
+    mix = g.add({"Mix": "Add"})
+    g.connect(e0, mix, 0, 0)
+    g.connect(e1, mix, 0, 1)
+    sep = g.add("SeparateRgba")
+    g.connect(mix, sep, 0, 0)
+    h2n = g.add("HeightToNormal")
+    g.connect(sep, h2n, 0, 0)
+    imgs = {0: [splitmix_plane(SEED_A, c, S, S) for c in range(4)], 1: [splitmix_plane(SEED_B, c, s, s) for c in range(4)]}
+    tp, lg = build(kc, g.dict(), imgs)
+    whole = lg.await_clean(h2n).slot_data(h2n, 0).image.planes()
+    parts = [lg.evaluate_band(h2n, y0, y1).planes() for (y0, y1) in ((0, 2048), (2048, 4096))]
+    assert_planes([np.concatenate([p[c] for p in parts], axis=0) for c in range(4)], whole, what="4096 bands")
