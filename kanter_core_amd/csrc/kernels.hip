@@ -9,7 +9,19 @@
 // Reference paths are relative to the reference checkout.
 #include "kc_internal.hpp"
 
+#include <cstdlib>
+
 namespace kc {
+
+// Grid cap of the grid-stride streaming kernels (to_u8, from_u8, height_to_normal); KC_TUNE_CAP overrides (tuning).
+static uint64_t grid_cap(uint64_t dflt)
+{
+    static long v = [] {
+        const char *e = std::getenv("KC_TUNE_CAP");
+        return e ? std::atol(e) : 0L;
+    }();
+    return v > 0 ? (uint64_t)v : dflt;
+}
 
 static __device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
 
@@ -24,14 +36,15 @@ static __device__ __forceinline__ float4 splat4(float v) { return make_float4(v,
 
 static __device__ __noinline__ float pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
 
-static __device__ __forceinline__ float kc_powf(float a, float b)
+// `tab`: what pow_setup() returned (the LDS copy of kPowTab + coefficients); only the pow codes read it
+static __device__ __forceinline__ float kc_powf(float a, float b, const PowCtx *tab)
 {
-    if (a > 0.0f && a < __builtin_inff() && __builtin_fabsf(b) < __builtin_inff()) return pow_positive(a, b);
+    if (a > 0.0f && a < __builtin_inff() && __builtin_fabsf(b) < __builtin_inff()) return pow_positive(a, b, *tab);
     return pow_general(a, b);
 }
 
 template <int CODE>
-static __device__ __forceinline__ float apply1(float acc, float x, float c = 0.0f)
+static __device__ __forceinline__ float apply1(float acc, float x, float c = 0.0f, const PowCtx *tab = nullptr)
 {
     if constexpr (CODE == CH_ADD_INV) return c - (acc + x);
     else if constexpr (CODE == CH_SUBL_INV) return c - (acc - x);
@@ -43,8 +56,8 @@ static __device__ __forceinline__ float apply1(float acc, float x, float c = 0.0
     else if constexpr (CODE == CH_MUL) return acc * x;
     else if constexpr (CODE == CH_DIV_L) return acc / x;
     else if constexpr (CODE == CH_DIV_R) return x / acc;
-    else if constexpr (CODE == CH_POW_L) return kc_powf(acc, x);
-    else if constexpr (CODE == CH_POW_R) return kc_powf(x, acc);
+    else if constexpr (CODE == CH_POW_L) return kc_powf(acc, x, tab);
+    else if constexpr (CODE == CH_POW_R) return kc_powf(x, acc, tab);
     else if constexpr (CODE == CH_ADD_R) return x + acc;
     else return x * acc;
 }
@@ -55,26 +68,26 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // loop ping-pongs between two register sets, so no switch arm ever has to preserve or merge the
 // old accumulator and the step costs exactly one packed VALU instruction per pixel pair.
 template <int CODE, int U>
-static __device__ __forceinline__ void apply4(f4 (&dst)[U], const f4 (&src)[U], const f4 (&x)[U], float c)
+static __device__ __forceinline__ void apply4(f4 (&dst)[U], const f4 (&src)[U], const f4 (&x)[U], float c, const PowCtx *tab)
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        dst[u].x = apply1<CODE>(src[u].x, x[u].x, c);
-        dst[u].y = apply1<CODE>(src[u].y, x[u].y, c);
-        dst[u].z = apply1<CODE>(src[u].z, x[u].z, c);
-        dst[u].w = apply1<CODE>(src[u].w, x[u].w, c);
+        dst[u].x = apply1<CODE>(src[u].x, x[u].x, c, tab);
+        dst[u].y = apply1<CODE>(src[u].y, x[u].y, c, tab);
+        dst[u].z = apply1<CODE>(src[u].z, x[u].z, c, tab);
+        dst[u].w = apply1<CODE>(src[u].w, x[u].w, c, tab);
     }
 }
 
 template <int CODE, int U>
-static __device__ __forceinline__ void apply4c(f4 (&dst)[U], const f4 (&src)[U], float c)
+static __device__ __forceinline__ void apply4c(f4 (&dst)[U], const f4 (&src)[U], float c, const PowCtx *tab)
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        dst[u].x = apply1<CODE>(src[u].x, c);
-        dst[u].y = apply1<CODE>(src[u].y, c);
-        dst[u].z = apply1<CODE>(src[u].z, c);
-        dst[u].w = apply1<CODE>(src[u].w, c);
+        dst[u].x = apply1<CODE>(src[u].x, c, 0.0f, tab);
+        dst[u].y = apply1<CODE>(src[u].y, c, 0.0f, tab);
+        dst[u].z = apply1<CODE>(src[u].z, c, 0.0f, tab);
+        dst[u].w = apply1<CODE>(src[u].w, c, 0.0f, tab);
     }
 }
 
@@ -118,7 +131,8 @@ static __device__ __forceinline__ void apply4c(f4 (&dst)[U], const f4 (&src)[U],
 
 // Runs the whole step program on the U float4 a thread holds: acc = start, then every step.
 template <int K, int U, int MODE>
-static __device__ __forceinline__ void chain_run(const ChainProgram &P, const uint32_t b, const f4 (&in)[K][U], f4 (&acc)[U])
+static __device__ __forceinline__ void chain_run(const ChainProgram &P, const uint32_t b, const f4 (&in)[K][U], f4 (&acc)[U],
+                                                 const PowCtx *tab = nullptr)
 {
     if (P.start_src < 0) {
 #pragma unroll
@@ -156,11 +170,11 @@ static __device__ __forceinline__ void chain_run(const ChainProgram &P, const ui
     const ChainStepPair *pp = P.step[b];  // two records per 16-byte scalar load, fetched one pair ahead
     ChainStepPair nxt = pp[0];
     f4 alt[U];
-#define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, U>(DST, SRC, c)
-#define KC_APPLY_0(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[0], c)
-#define KC_APPLY_1(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0], c)
-#define KC_APPLY_2(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0], c)
-#define KC_APPLY_3(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0], c)
+#define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, U>(DST, SRC, c, tab)
+#define KC_APPLY_0(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[0], c, tab)
+#define KC_APPLY_1(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 1 ? 1 : 0], c, tab)
+#define KC_APPLY_2(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 2 ? 2 : 0], c, tab)
+#define KC_APPLY_3(CODE, DST, SRC) apply4<CODE, U>(DST, SRC, in[K > 3 ? 3 : 0], c, tab)
 #define KC_STEP(DST, SRC, REC)                                                          \
     {                                                                                   \
         const uint32_t w = (REC).word;                                                  \
@@ -200,6 +214,10 @@ static __device__ __forceinline__ void chain_run(const ChainProgram &P, const ui
 template <int K, int U, int MODE>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
 {
+    __shared__ double pow_lds[MODE >= 2 ? KC_POW_TABLE_DOUBLES : 1];
+    PowCtx pw{};
+    if constexpr (MODE >= 2) pw = pow_setup(pow_lds);
+    const PowCtx *pow_tab = &pw;
     const uint32_t b = blockIdx.y;
     const uint32_t total = P.rows * P.row_units;
     const bool flat = P.rows == 1;
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
                 in[k][u] = idx < total ? inp[k][row * ipitch[k] + col] : f4{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
 
-        chain_run<K, U, MODE>(P, b, in, acc);
+        chain_run<K, U, MODE>(P, b, in, acc, pow_tab);
 
         // output offsets are recomputed here rather than kept live across the program (VGPRs)
 #pragma unroll
@@ -250,6 +268,10 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
 template <int MODE>
 __global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
 {
+    __shared__ double pow_lds[MODE >= 2 ? KC_POW_TABLE_DOUBLES : 1];
+    PowCtx pw{};
+    if constexpr (MODE >= 2) pw = pow_setup(pow_lds);
+    const PowCtx *tab = &pw;
     const uint32_t b = blockIdx.y;
     const uint32_t total = P.rows * P.row_units;
     const bool flat = P.rows == 1;
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
         const uint32_t w = r.word;
         const float c = r.c;
         f4 nxt[1];
-#define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, 1>(DST, SRC, c)
+#define KC_APPLY_C(CODE, DST, SRC) apply4c<CODE, 1>(DST, SRC, c, tab)
         KC_CODE_SWITCH(KC_APPLY_C, nxt, acc)
 #undef KC_APPLY_C
         acc[0] = nxt[0];
@@ -956,7 +978,7 @@ hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w
     const uint64_t total = (uint64_t)((w + 3) / 4) * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > grid_cap(8192)) blocks = grid_cap(8192);
     if (band)
         height_to_normal_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch);
     else
@@ -978,19 +1000,19 @@ static __device__ __forceinline__ uint32_t quant_u8(float v)
     return (uint32_t)x;               // 0 <= x <= 255: truncation
 }
 
-static __device__ __forceinline__ float srgb_to_linear(float s)
+static __device__ __forceinline__ float srgb_to_linear(float s, const PowCtx *tab)
 {
     if (s <= 0.0f) return s;
     if (s <= 0.04045f) return s / 12.92f;
-    return kc_powf((s + 0.055f) / 1.055f, 2.4f);
+    return kc_powf((s + 0.055f) / 1.055f, 2.4f, tab);
 }
 
-static __device__ __forceinline__ uint32_t quant_u8_srgb(float v)
+static __device__ __forceinline__ uint32_t quant_u8_srgb(float v, const PowCtx *tab)
 {
     float x = v;
     if (x < 0.0f) x = 0.0f;
     if (x > 1.0f) x = 1.0f;
-    x = srgb_to_linear(x) * 255.0f;
+    x = srgb_to_linear(x, tab) * 255.0f;
     if (!(x <= 255.0f)) x = 255.0f;
     return (uint32_t)x;
 }
@@ -1005,6 +1027,10 @@ template <bool SRGB>
 __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operand b, Operand a, int gray, uint32_t w,
                                                     uint32_t h, uint8_t *__restrict__ dst)
 {
+    __shared__ double pow_lds[SRGB ? KC_POW_TABLE_DOUBLES : 1];
+    PowCtx pw{};
+    if constexpr (SRGB) pw = pow_setup(pow_lds);
+    const PowCtx *pow_tab = &pw;
     const uint32_t row_units = (w + 3) / 4;
     const uint32_t total = row_units * h;
     for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -1016,7 +1042,7 @@ __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operan
         if (gray) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t v = SRGB ? quant_u8_srgb(rr[e]) : quant_u8(rr[e]);
+                const uint32_t v = SRGB ? quant_u8_srgb(rr[e], pow_tab) : quant_u8(rr[e]);
                 px[e] = v | (v << 8) | (v << 16) | (255u << 24);
             }
         } else {
@@ -1028,9 +1054,9 @@ __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operan
             float aa[4] = { va.x, va.y, va.z, va.w };
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t qr = SRGB ? quant_u8_srgb(rr[e]) : quant_u8(rr[e]);
-                const uint32_t qg = SRGB ? quant_u8_srgb(gg[e]) : quant_u8(gg[e]);
-                const uint32_t qb = SRGB ? quant_u8_srgb(bb[e]) : quant_u8(bb[e]);
+                const uint32_t qr = SRGB ? quant_u8_srgb(rr[e], pow_tab) : quant_u8(rr[e]);
+                const uint32_t qg = SRGB ? quant_u8_srgb(gg[e], pow_tab) : quant_u8(gg[e]);
+                const uint32_t qb = SRGB ? quant_u8_srgb(bb[e], pow_tab) : quant_u8(bb[e]);
                 const uint32_t qa = quant_u8(aa[e]);
                 px[e] = qr | (qg << 8) | (qb << 16) | (qa << 24);
             }
@@ -1052,7 +1078,7 @@ hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, in
     const uint64_t total = (uint64_t)((w + 3) / 4) * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > grid_cap(8192)) blocks = grid_cap(8192);
     if (srgb)
         to_u8_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
     else
@@ -1090,7 +1116,7 @@ hipError_t launch_from_u8(const uint8_t *src, int channels, uint32_t w, uint32_t
     const uint64_t total = (uint64_t)w * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > grid_cap(8192)) blocks = grid_cap(8192);
     from_u8_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(src, channels, w, h, planes[0], planes[1], planes[2],
                                                           planes[3], pitch);
     return hipGetLastError();

@@ -37,6 +37,8 @@ static __device__ __forceinline__ int ulp_diff(float x, float y)
 // mode 2: a = 1 +- tiny, b large (|b log2 a| up to ~150)
 __global__ void check(uint64_t n, int mode, uint64_t seed, unsigned long long *diff, int *maxd, uint32_t *worst)
 {
+    __shared__ double lds[KC_POW_TABLE_DOUBLES];
+    const PowCtx tab = pow_setup(lds);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = splitmix(seed + i), r2 = splitmix(r);
         float a, b;
@@ -54,7 +56,7 @@ __global__ void check(uint64_t n, int mode, uint64_t seed, unsigned long long *d
             b = (float)((double)(int64_t)(r2 >> 20) * 0x1p-44 * 2.0e8 - 1.0e8);
         }
         const float want = (float)pow((double)a, (double)b);
-        const float got = pow_positive(a, b);
+        const float got = pow_positive(a, b, tab);
         const int d = ulp_diff(got, want);
         if (d) {
             atomicAdd(diff, 1ull);

@@ -31,7 +31,7 @@ def test_every_step_code_compiles(flat):
     const_codes = [ADD, SUB_L, SUB_R, MUL, DIV_L, DIV_R, POW_L, POW_R]
     words = [word(c, i % 4) for i, c in enumerate(plane_codes)] + [word(c, -1) for c in const_codes]
     src = kc.specialize_compile_check(words, n_in=4, start_src=3, flat=flat)
-    assert "pow4(acc, in2)" in src and "pow_positive" in src
+    assert "pow4(acc, in2, pow_tab)" in src and "pow_positive" in src
     assert ("idx / P.row_units" in src) == (not flat)
 
 
