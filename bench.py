@@ -318,6 +318,8 @@ def main():
     # fusion pattern is decided at run time (fanin: the add tree continues some of the branch chains) it is the figure.
     formula_bytes = alg_bytes
     alg_bytes = counted[0]
+    if kc.specialize_stats()["specialized_launches"] and "chain_kernel<" in kernel:
+        kernel = "kc_chain_<hash> (the chain program compiled to straight-line code at run time, csrc/specialize.cpp; " + kernel + " = the interpreter, first sightings only)"
     main_step_us = step_spread(step, max(20, min(args.steps, 100)))
     total_px = node_px
     if world > 1:
@@ -331,14 +333,21 @@ def main():
     per_step_s = dev_s / args.steps             # HIP events on the launch stream over the timed region
     launches_per_step = launches / args.steps
     achieved = alg_bytes / per_step_s / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_resize_chain_kernel.json" if args.workload == "resize_blend" else "pmc_chain_kernel.json")
-    if os.path.exists(pmc) and S == 4096 and ((args.workload == "chain32" and N == 32) or args.workload == "resize_blend"):
+    # HBM traffic by PMC counters is collected in separate rocprofv3 --pmc passes (profiles/run_pmc.sh), never inside
+    # this run: the figure below is read from the committed capture and labelled with its source; it is dropped when
+    # the capture is of another kernel than the one this run launched.
+    traffic = traffic_source = None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_resize_chain_kernel.json" if args.workload == "resize_blend" else "r02_pmc_chain_kernel.json")
+    if os.path.exists(pmc) and S == 4096 and ((args.workload == "chain32" and N == 32 and band is None) or args.workload == "resize_blend"):
         try:
             with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                cap = json.load(f)
+            ran_specialized = bool(kc.specialize_stats()["specialized_launches"])
+            if args.workload == "resize_blend" or (("kc_chain_" in cap.get("kernel", "")) == ran_specialized):
+                traffic = cap.get("hbm_bytes_per_launch")
+                traffic_source = "%s (kernel %s; %s)" % (os.path.relpath(pmc, ROOT), cap.get("kernel"), cap.get("captured") or "capture note missing")
         except Exception:
-            traffic = None
+            traffic = traffic_source = None
 
     headline = args.workload == "chain32" and S == 4096 and N == 32 and not band_note
     out = {
@@ -362,7 +371,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_step, 1.0) if launches_per_step else alg_bytes,
             "algorithmic_bytes_per_step": alg_bytes, "closed_form_bytes_per_step": formula_bytes,
             "kernel_us": round(per_step_s / max(launches_per_step, 1.0) * 1e6, 2),
@@ -426,6 +435,8 @@ def main():
             orc.set_threads(1)
             out["cpu_baseline_all_cores"] = {"value": round(float(N) * S * S * 3 / mt_s / 1e6, 2), "unit": "Mpix/s",
                                              "cores": threads, "kind": "port",
+                                             "note": "a reported baseline, not a target: %d of the box's %d cores (one GPU's share); the port keeps the "
+                                                     "reference's per-node plane allocation and first touch, which do not parallelise" % (threads, os.cpu_count() or 1),
                                              "sample": "3 evaluations, rows split over %d OpenMP threads = one GPU's share of the box's %d host cores (%.1f s)" % (threads, os.cpu_count() or 1, mt_s)}
         # parity of the timed workload against the oracle, on the same inputs
         got = g[0].slot_data(g[3], 0).image.planes()

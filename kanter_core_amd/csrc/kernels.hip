@@ -14,6 +14,8 @@
 namespace kc {
 
 // Grid cap of the grid-stride streaming kernels (to_u8, from_u8, height_to_normal); KC_TUNE_CAP overrides (tuning).
+// Default: no cap, one quad / pixel per thread -- from_u8 58.1 -> 50.4 us, height_to_normal 56.8 -> 55.4 us at 4096^2
+// against 8192 workgroups looping twice (profiles/r02_kernel_times.txt); to_u8 does not care.
 static uint64_t grid_cap(uint64_t dflt)
 {
     static long v = [] {
@@ -936,6 +938,98 @@ static __device__ __forceinline__ void h2n_px(float px, float up, float left, fl
     b = nz * 0.5f + 0.5f;
 }
 
+// The same arithmetic for the 4 pixels of a quad at once, written on 4-wide vectors so that the Newton / residual
+// steps of the shared-denominator division and of the square root become packed instructions (v_pk_fma_f32,
+// v_pk_mul_f32: two pixels per instruction) -- this kernel is bound by vector-instruction issue, not by HBM.
+// Element by element these are exactly the operations of h2n_px's `tame` branch (same instructions, same order);
+// a quad with any pixel outside that range goes through h2n_px pixel by pixel.
+static __device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
+static __device__ __forceinline__ f4 rcp4(f4 x)
+{
+    return f4{ __builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y), __builtin_amdgcn_rcpf(x.z), __builtin_amdgcn_rcpf(x.w) };
+}
+static __device__ __forceinline__ f4 rsq4(f4 x)
+{
+    return f4{ __builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y), __builtin_amdgcn_rsqf(x.z), __builtin_amdgcn_rsqf(x.w) };
+}
+static __device__ __forceinline__ f4 copysign4(f4 mag, f4 sgn)
+{
+    return f4{ __builtin_copysignf(mag.x, sgn.x), __builtin_copysignf(mag.y, sgn.y), __builtin_copysignf(mag.z, sgn.z),
+               __builtin_copysignf(mag.w, sgn.w) };
+}
+static __device__ __forceinline__ f4 sqrt_normal4(f4 x)
+{
+    const f4 half = { 0.5f, 0.5f, 0.5f, 0.5f };
+    const f4 y = rsq4(x);
+    const f4 s0 = x * y;
+    const f4 h0 = y * half;
+    const f4 e = fma4(-h0, s0, half);
+    const f4 h = fma4(h0, e, h0);
+    const f4 s = fma4(s0, e, s0);
+    const f4 d = fma4(-s, s, x);
+    return fma4(d, h, s);
+}
+struct SharedDenominator4 {
+    f4 nb, r;
+};
+static __device__ __forceinline__ SharedDenominator4 shared_denominator4(f4 b)
+{
+    const f4 one = { 1.0f, 1.0f, 1.0f, 1.0f };
+    const f4 r0 = rcp4(b);
+    const f4 e = fma4(-b, r0, one);
+    return { -b, fma4(e, r0, r0) };
+}
+template <bool MAY_BE_ZERO = true>
+static __device__ __forceinline__ f4 divide_by4(const SharedDenominator4 &d, f4 a)
+{
+    const f4 m = a * d.r;
+    const f4 f2 = fma4(d.nb, m, a);
+    const f4 f3 = fma4(f2, d.r, m);
+    const f4 f4_ = fma4(d.nb, f3, a);
+    const f4 q = fma4(f4_, d.r, f3);
+    return MAY_BE_ZERO ? copysign4(q, a) : q;
+}
+
+static __device__ __forceinline__ bool tame1(float d)
+{
+    const float a = fabsf(d);
+    return d == 0.0f || (a >= 0x1p-40f && a <= 0x1p7f);
+}
+
+// px, up, left: the quad's heights, the heights above them, the heights to their left
+static __device__ __forceinline__ void h2n_quad(f4 px, f4 up, f4 left, float pdx, float pdy, f4 &r, f4 &g, f4 &b)
+{
+    const f4 tz0 = px - left, bz0 = up - px;
+    const bool tame = tame1(tz0.x) && tame1(tz0.y) && tame1(tz0.z) && tame1(tz0.w) && tame1(bz0.x) && tame1(bz0.y) &&
+                      tame1(bz0.z) && tame1(bz0.w);
+    if (!tame) {
+        float rr[4], gg[4], bb[4];
+        h2n_px(px.x, up.x, left.x, pdx, pdy, rr[0], gg[0], bb[0]);
+        h2n_px(px.y, up.y, left.y, pdx, pdy, rr[1], gg[1], bb[1]);
+        h2n_px(px.z, up.z, left.z, pdx, pdy, rr[2], gg[2], bb[2]);
+        h2n_px(px.w, up.w, left.w, pdx, pdy, rr[3], gg[3], bb[3]);
+        r = f4{ rr[0], rr[1], rr[2], rr[3] };
+        g = f4{ gg[0], gg[1], gg[2], gg[3] };
+        b = f4{ bb[0], bb[1], bb[2], bb[3] };
+        return;
+    }
+    const f4 vdx = { pdx, pdx, pdx, pdx }, vdy = { pdy, pdy, pdy, pdy }, half = { 0.5f, 0.5f, 0.5f, 0.5f };
+    const f4 zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    const f4 q1 = vdx * vdx + tz0 * tz0, q2 = vdy * vdy + bz0 * bz0;
+    const SharedDenominator4 d1 = shared_denominator4(sqrt_normal4(q1)), d2 = shared_denominator4(sqrt_normal4(q2));
+    const f4 tx = divide_by4<false>(d1, vdx), tz = divide_by4(d1, tz0);
+    const f4 by = divide_by4<false>(d2, vdy), bz = divide_by4(d2, bz0);
+    const f4 ty = zero, bx = zero;  // 0 / n
+    const f4 cx = ty * bz - tz * by;
+    const f4 cy = tz * bx - tx * bz;
+    const f4 cz = tx * by - ty * bx;
+    const SharedDenominator4 d3 = shared_denominator4(sqrt_normal4((cx * cx + cy * cy) + cz * cz));
+    const f4 nx = divide_by4(d3, cx), ny = divide_by4(d3, cy), nz = divide_by4<false>(d3, cz);
+    r = nx * half + half;
+    g = ny * half + half;
+    b = nz * half + half;
+}
+
 // BAND = false: the whole plane, rows wrap around (row -1 = row h - 1).  BAND = true: a row band -- `hgt` holds
 // h + 1 rows, the band's rows preceded by the row above its first one (the caller's halo: the previous band's last
 // row, or the image's last row for the band that starts at row 0); `full_h` is the height of the whole image, which
@@ -956,18 +1050,15 @@ __global__ __launch_bounds__(256) void height_to_normal_kernel(const float *__re
         const uint32_t yc = BAND ? y + 1 : y;                          // row of this pixel in `hgt`
         const uint32_t yu = BAND ? y : (y == 0 ? h - 1 : y - 1);       // row above it
         const float *rowp = hgt + (size_t)yc * hpitch;
-        const float4 cur = *reinterpret_cast<const float4 *>(rowp + 4 * q);
-        const float4 upv = *reinterpret_cast<const float4 *>(hgt + (size_t)yu * hpitch + 4 * q);
+        const f4 cur = *reinterpret_cast<const f4 *>(rowp + 4 * q);
+        const f4 upv = *reinterpret_cast<const f4 *>(hgt + (size_t)yu * hpitch + 4 * q);
         const float lft = q == 0 ? rowp[w - 1] : rowp[4 * q - 1];
-        float4 r, g, b;
-        h2n_px(cur.x, upv.x, lft, pdx, pdy, r.x, g.x, b.x);
-        h2n_px(cur.y, upv.y, cur.x, pdx, pdy, r.y, g.y, b.y);
-        h2n_px(cur.z, upv.z, cur.y, pdx, pdy, r.z, g.z, b.z);
-        h2n_px(cur.w, upv.w, cur.z, pdx, pdy, r.w, g.w, b.w);
+        f4 r, g, b;
+        h2n_quad(cur, upv, f4{ lft, cur.x, cur.y, cur.z }, pdx, pdy, r, g, b);
         const size_t o = (size_t)y * opitch + 4 * q;
-        *reinterpret_cast<float4 *>(nx + o) = r;
-        *reinterpret_cast<float4 *>(ny + o) = g;
-        *reinterpret_cast<float4 *>(nz + o) = b;
+        *reinterpret_cast<f4 *>(nx + o) = r;
+        *reinterpret_cast<f4 *>(ny + o) = g;
+        *reinterpret_cast<f4 *>(nz + o) = b;
     }
 }
 
@@ -978,7 +1069,7 @@ hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w
     const uint64_t total = (uint64_t)((w + 3) / 4) * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
-    if (blocks > grid_cap(8192)) blocks = grid_cap(8192);
+    if (blocks > grid_cap(1u << 30)) blocks = grid_cap(1u << 30);
     if (band)
         height_to_normal_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch);
     else
@@ -1078,7 +1169,7 @@ hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, in
     const uint64_t total = (uint64_t)((w + 3) / 4) * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
-    if (blocks > grid_cap(8192)) blocks = grid_cap(8192);
+    if (blocks > grid_cap(1u << 30)) blocks = grid_cap(1u << 30);
     if (srgb)
         to_u8_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
     else
@@ -1116,7 +1207,7 @@ hipError_t launch_from_u8(const uint8_t *src, int channels, uint32_t w, uint32_t
     const uint64_t total = (uint64_t)w * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
-    if (blocks > grid_cap(8192)) blocks = grid_cap(8192);
+    if (blocks > grid_cap(1u << 30)) blocks = grid_cap(1u << 30);
     from_u8_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(src, channels, w, h, planes[0], planes[1], planes[2],
                                                           planes[3], pitch);
     return hipGetLastError();

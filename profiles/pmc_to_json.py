@@ -20,15 +20,17 @@ for f in glob.glob(os.path.join(src, "pass*", "**", "*counter_collection.csv"), 
     for r in csv.DictReader(open(f)):
         d = per[r["Kernel_Name"]][r["Counter_Name"]]
         d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
-kernel = max((k for k in per if "chain_kernel" in k), key=lambda k: len(per[k].get("WRITE_SIZE", {})))
+want = sys.argv[5] if len(sys.argv) > 5 else "kc_chain_"  # substring of the kernel name; the one with most dispatches wins
+kernel = max((k for k in per if want in k), key=lambda k: len(per[k].get("WRITE_SIZE", {})))  # kc_chain_<hash> once specialised
 avg = {}
 for c, d in sorted(per[kernel].items()):
-    ids = sorted(d)[3:]  # bench.py --warmup 3
+    ids = sorted(d)[3:] if len(d) > 6 else sorted(d)  # bench.py --warmup 3 (the first sightings run the interpreter kernel)
     avg[c] = sum(d[i] for i in ids) / len(ids)
 fetch = avg["FETCH_SIZE"] * 1024.0 * 2.0
 write = avg["WRITE_SIZE"] * 1024.0
 json.dump({
     "kernel": kernel.split("(")[0].replace("void ", ""),
+    "captured": os.environ.get("KC_CAPTURE_NOTE", ""),
     "workload": what,
     "counters_avg_per_launch": {k: round(v, 1) for k, v in avg.items()},
     "fetch_bytes_corrected_x2": fetch,

@@ -5,7 +5,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline ${BENCH_EXTRA:-}"
+ARGS="$GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras ${BENCH_EXTRA:-}"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
