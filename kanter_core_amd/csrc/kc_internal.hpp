@@ -50,7 +50,9 @@ hipError_t launch_resize_horizontal(const float *tmp, uint32_t tpitch, float *ds
 constexpr uint32_t KC_RESIZE_REG_TAPS = 8;
 inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t v_stride, uint32_t tile_w, uint32_t h_stride)
 {
-    size_t n = (size_t)tile_h * ncp + 8u + 2u * tile_h + (size_t)tile_h * v_stride;
+    // the wide form pads its intermediate rows (one float after every 32, see resize_wide_kernel)
+    const size_t row = h_stride > KC_RESIZE_REG_TAPS ? (size_t)ncp + (ncp >> 5) + 1u : ncp;
+    size_t n = (size_t)tile_h * row + 8u + 2u * tile_h + (size_t)tile_h * v_stride;
     if (h_stride > KC_RESIZE_REG_TAPS) n += 2u * tile_w + (size_t)tile_w * h_stride;
     return n * sizeof(float);
 }

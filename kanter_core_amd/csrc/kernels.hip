@@ -486,10 +486,13 @@ static __device__ __forceinline__ void resize_load_cols(ResizeCols<MAXT> &C, con
 // beyond the loop counters (the scalar unit is shared by the CU's four SIMDs).
 // Taps every row of the tile has (j < vmin) are summed unconditionally; the remaining ones are
 // per-lane predicated: a tap past a lane's window repeats its last row and adds -0.0.
-template <int VU>
+// SWZ: the intermediate row is stored with one float of padding after every 32 (index i lives at i + (i >> 5)), the
+// layout resize_wide_kernel's horizontal pass reads without bank conflicts; `ncp4` is then unused and `ncp_swz` is the
+// row pitch in floats.
+template <int VU, bool SWZ = false>
 static __device__ __forceinline__ void resize_vpass_items(const f4 *__restrict__ src4, uint32_t sp4, f4 *tmp4, uint32_t ncp4,
                                                           uint32_t th, uint32_t nq, const uint32_t *vl, const uint32_t *vn,
-                                                          const float *vw, uint32_t vstride, uint32_t vmin)
+                                                          const float *vw, uint32_t vstride, uint32_t vmin, uint32_t ncp_swz = 0)
 {
     auto add = [](f4 &a, const f4 &px, float wt) {
         a.x += px.x * wt;
@@ -536,15 +539,26 @@ static __device__ __forceinline__ void resize_vpass_items(const f4 *__restrict__
                 acc.w += live ? p[u].w * wt[u] : -0.0f;
             }
         }
-        tmp4[ty * ncp4 + q] = acc;
+        if constexpr (SWZ) {
+            float *o = reinterpret_cast<float *>(tmp4) + ty * ncp_swz + 4u * q + (q >> 3);  // a quad never straddles a multiple of 32
+            o[0] = acc.x;
+            o[1] = acc.y;
+            o[2] = acc.z;
+            o[3] = acc.w;
+        } else {
+            tmp4[ty * ncp4 + q] = acc;
+        }
     }
 }
 
+// SWZ (resize_wide_kernel): rows of `tmp` are ncp + ncp / 32 + 1 floats apart and swizzled, see resize_vpass_items.
+template <bool SWZ = false>
 static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const float *__restrict__ src,
                                                                uint32_t spitch, uint32_t dw, uint32_t dh,
                                                                const TapsDev &V, const TapsDev &H, uint32_t tile_w,
                                                                uint32_t tile_h, uint32_t ncp)
 {
+    const uint32_t row_floats = SWZ ? ncp + (ncp >> 5) + 1u : ncp;
     ResizeTile T;
     T.x0 = blockIdx.x * tile_w;
     T.y0 = blockIdx.y * tile_h;
@@ -556,7 +570,7 @@ static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const
     const uint32_t nq = (H.left[T.x1 - 1] + H.count[T.x1 - 1] - T.c0 + 3u) / 4u;  // <= ncp / 4 (host-checked)
 
     // the tile rows' vertical taps: one coalesced fetch into LDS
-    uint32_t *vl = reinterpret_cast<uint32_t *>(lds + tile_h * ncp + 8u);
+    uint32_t *vl = reinterpret_cast<uint32_t *>(lds + tile_h * row_floats + 8u);
     uint32_t *vn = vl + tile_h;
     float *vw = reinterpret_cast<float *>(vn + tile_h);  // tile_h x V.stride
     for (uint32_t i = threadIdx.x; i < T.th; i += 256u) {
@@ -574,9 +588,9 @@ static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const
     const f4 *src4 = reinterpret_cast<const f4 *>(src + T.c0);
     f4 *tmp4 = reinterpret_cast<f4 *>(lds);
     if (V.stride <= 4u)
-        resize_vpass_items<4>(src4, spitch / 4u, tmp4, ncp / 4u, T.th, nq, vl, vn, vw, V.stride, vmin);
+        resize_vpass_items<4, SWZ>(src4, spitch / 4u, tmp4, ncp / 4u, T.th, nq, vl, vn, vw, V.stride, vmin, row_floats);
     else
-        resize_vpass_items<8>(src4, spitch / 4u, tmp4, ncp / 4u, T.th, nq, vl, vn, vw, V.stride, vmin);
+        resize_vpass_items<8, SWZ>(src4, spitch / 4u, tmp4, ncp / 4u, T.th, nq, vl, vn, vw, V.stride, vmin, row_floats);
     __syncthreads();
     return T;
 }
@@ -666,13 +680,18 @@ __global__ __launch_bounds__(256) void resize_wide_kernel(const ResizePlanes P, 
         hn[i] = H.count[x0 + i];
     }
     for (uint32_t i = threadIdx.x; i < tw * H.stride; i += 256u) hw[i] = H.w[(size_t)x0 * H.stride + i];
-    const ResizeTile T = resize_tile_vpass(lds, src, spitch, dw, dh, V, H, tile_w, tile_h, ncp);  // its barriers publish hl/hn/hw
+    const ResizeTile T = resize_tile_vpass<true>(lds, src, spitch, dw, dh, V, H, tile_w, tile_h, ncp);  // its barriers publish hl/hn/hw
+    const uint32_t row_floats = ncp + (ncp >> 5) + 1u;
     const uint32_t sh = 31u - (uint32_t)__clz((int)tile_w);  // tile_w is a power of two
     for (uint32_t i = threadIdx.x; i < T.th * tile_w; i += 256u) {
         const uint32_t ty = i >> sh, x = i & (tile_w - 1u);
         if (x >= tw) continue;
         const uint32_t n = hn[x];
-        const float *row = T.tmp + ty * ncp + hl[x];
+        // Neighbouring outputs read windows `ratio` floats apart: straight indexing put the 32 lanes of a pass on 8 (ratio 4)
+        // or 4 (ratio 8) banks -- PMC: 65 % of this pass's LDS cycles were bank conflicts.  The intermediate row is stored
+        // with one float of padding after every 32 (resize_vpass_items<.., true>), which spreads strides 2, 4 and 8 over all banks.
+        const float *row = T.tmp + ty * row_floats;
+        const uint32_t h0 = hl[x];
         const float *w = hw + x * H.stride;
         float t = 0.0f;
         for (uint32_t j0 = 0; j0 < n; j0 += 4u) {
@@ -680,7 +699,8 @@ __global__ __launch_bounds__(256) void resize_wide_kernel(const ResizePlanes P, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t jj = min(j0 + u, n - 1u);
-                p[u] = row[jj];
+                const uint32_t idx = h0 + jj;
+                p[u] = row[idx + (idx >> 5)];
                 wt[u] = w[jj];
             }
 #pragma unroll
@@ -799,7 +819,7 @@ hipError_t launch_resize_lds(const ResizePlanes &p, int batch, uint32_t dw, uint
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h, batch);
     if (h.stride > KC_RESIZE_REG_TAPS)
         resize_wide_kernel<<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, tile_h, ncp,
-                                                  (uint32_t)(resize_lds_bytes(tile_h, ncp, v.stride, 0, 0) / sizeof(float)));
+                                                  (uint32_t)(lds / sizeof(float) - (2u * tile_w + (size_t)tile_w * h.stride)));
     else if (h_min_count >= 2)
         launch_resize_lds_t<2>(grid, lds, s, h.stride, p, dw, dh, v, h, tile_w, tile_h, ncp);
     else

@@ -280,9 +280,11 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
     if (c.resize_tile_w > 0 && c.resize_tile_h > 0 &&  // tuning override (KC_RESIZE_TILE_W / _H)
         tile_fits(tv, th, size, (uint32_t)c.resize_tile_w, (uint32_t)c.resize_tile_h, 64 * 1024, t))
         return t;
-    // Wide horizontal windows (down-sampling): the vertical pass re-reads window rows per output row,
-    // so small tiles -- many workgroups, short dependent chains -- win (profiles/resize_tile_sweep.py).
-    static const uint32_t wide[][2] = { { 32, 4 }, { 16, 4 }, { 8, 4 }, { 4, 4 } };
+    // Wide horizontal windows (down-sampling): the vertical pass re-reads window rows per output row, so small tiles --
+    // many workgroups, short dependent chains -- win (profiles/resize_tile_sweep.py).  With the intermediate rows
+    // swizzled (no LDS bank conflicts in the horizontal pass) 64 x 8 is the best all-rounder: Lanczos3 4x 37.9 -> 36.3 us,
+    // CatmullRom 3x 45.8 -> 33.3, Gaussian 4.3x 25.9 -> 25.2, Triangle 8x 19.9 -> 20.6 (profiles/r02_wide_tiles.txt).
+    static const uint32_t wide[][2] = { { 64, 8 }, { 32, 4 }, { 16, 4 }, { 8, 4 }, { 4, 4 } };
     static const uint32_t tiles[][2] = { { 1024, 16 }, { 1024, 8 }, { 512, 16 }, { 512, 8 }, { 256, 16 }, { 256, 8 },
                                          { 128, 16 },  { 128, 8 },  { 64, 8 },   { 32, 8 },  { 16, 8 },   { 16, 4 },
                                          { 8, 4 },     { 4, 4 } };
