@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: node-Mpix/s of the 32-node linear mix/invert graph on 4096x4096 f32x4
-(BASELINE.json metric; SURVEY.md 8(d) config #3 at 4096^2), per MI355X, plus the HBM roofline
+(BASELINE.json metric; SURVEY.md 8(d) config #3 at 4096^2) on one MI355X, plus the HBM roofline
 fraction of the dominant kernel and the CPU oracle timed on this box's host cores.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload chain32] [--size 4096] [--nodes 32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ...] [--size 4096] [--nodes 32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one full evaluation of the graph (every node over every pixel) on inputs already
-resident in HBM.  With N > 1 every rank evaluates its own graph on its own GPU (independent
-graphs: no data-path collective, weak scaling); the time is the max over ranks.  Rank 0 prints
-ONE JSON line.
+resident in HBM.  Rank 0 prints ONE JSON line.
 
-Other workloads (parity-tested configs of BASELINE.json, reported in DESIGN.md, not the headline):
+Default workload:
+    N = 1   chain32: the headline.  One launch per step (the 32 nodes are one fused chain); from the third
+            evaluation on it is the run-time specialised kernel (csrc/specialize.cpp; the warm-up waits for the compile).
+    N > 1   fanin: BASELINE config #4 -- 8 independent 16-node subgraphs + a 7-node Mix(Add) tree as ONE graph that
+            the library's partitioner (kc_live_graph_partition) spreads over the ranks; branch results go to the home
+            rank as grouped RCCL send/recv of the planes, the join runs there.  "scaling": "strong" (fixed total work);
+            per-rank host compute / exchange times are in "per_rank".  Compare with --gpus 1 --workload fanin.
+
+Other workloads (parity-tested configs of BASELINE.json, reported in DESIGN.md):
     --workload mix1           config #1: one Mix(Add) node, two 4096^2 f32x4 inputs
     --workload resize_blend   config #2: 512^2 -> 4096^2 Triangle resize + 3-node blend chain
-    --workload chain32 --size 8192   config #3 at its full size
-    --workload chain32_rows --size 8192   config #3 split by row bands over the ranks (strong scaling:
-                              a pointwise graph needs no exchange, every rank owns rows [y0, y1) of every plane)
-    --workload fanin          config #4: 8 independent 16-node subgraphs, results gathered to rank 0
-                              over RCCL and summed by a 7-node Mix(Add) tree
+    --workload chain32 --size 8192   config #3 at its full size (with N > 1: an independent graph per GPU, weak scaling)
+    --workload chain32_rows --size 8192   config #3 split by row bands over the ranks through the library's band path
+                              (kc_live_graph_evaluate_band; strong scaling, no exchange)
+    --workload fanin          config #4 (any N, also N = 1)
+Every workload run with N = 1 also carries a "parity" object: the timed graph's result against the oracle.
 """
 import argparse
 import json
