@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P,
     // the expensive part, see chain_run); rows past the tile repeat its last row and are not stored.
     // With one resident input, its quads for trip i + 1 are requested before trip i is computed (the
     // first before the vertical pass): a wave then never waits for loads queued behind its own stores.
-    constexpr int RU = 4;
+    constexpr int RU = KC_FUSED_RU;
     constexpr bool AHEAD = K <= 2;  // 16 more registers per resident input: not worth the occupancy beyond one
     f4 nxt[KM][RU];
     auto request = [&](uint32_t ty0) {
@@ -977,9 +977,17 @@ static __device__ __forceinline__ f4 copysign4(f4 mag, f4 sgn)
     return f4{ __builtin_copysignf(mag.x, sgn.x), __builtin_copysignf(mag.y, sgn.y), __builtin_copysignf(mag.z, sgn.z),
                __builtin_copysignf(mag.w, sgn.w) };
 }
-static __device__ __forceinline__ f4 sqrt_normal4(f4 x)
+struct SharedDenominator4 {
+    f4 nb, r;
+};
+// The denominator-only part of the division by n = sqrt_normal(x), with the reciprocal seeded by the rsq the square root
+// starts from anyway instead of a separate v_rcp_f32 of n: y = rsq(x) is 1 / n to ~2^-22, one Newton step on n takes it to
+// the same ~2^-45 the rcp-seeded step reaches, and the quotient's correction steps are the same.  Transcendental
+// instructions run at a quarter of the packed-math rate: this halves them (6 -> 3 per pixel).  Checked against a / sqrtf(x)
+// over 3 x 2^34 (a, x) pairs in the ranges h2n_quad establishes (profiles/exact_math_check.hip, r02_exact_math_check.txt).
+static __device__ __forceinline__ SharedDenominator4 sqrt_denominator4(f4 x)
 {
-    const f4 half = { 0.5f, 0.5f, 0.5f, 0.5f };
+    const f4 half = { 0.5f, 0.5f, 0.5f, 0.5f }, one = { 1.0f, 1.0f, 1.0f, 1.0f };
     const f4 y = rsq4(x);
     const f4 s0 = x * y;
     const f4 h0 = y * half;
@@ -987,18 +995,11 @@ static __device__ __forceinline__ f4 sqrt_normal4(f4 x)
     const f4 h = fma4(h0, e, h0);
     const f4 s = fma4(s0, e, s0);
     const f4 d = fma4(-s, s, x);
-    return fma4(d, h, s);
+    const f4 n = fma4(d, h, s);  // sqrt_normal4(x)
+    const f4 er = fma4(-n, y, one);
+    return { -n, fma4(er, y, y) };
 }
-struct SharedDenominator4 {
-    f4 nb, r;
-};
-static __device__ __forceinline__ SharedDenominator4 shared_denominator4(f4 b)
-{
-    const f4 one = { 1.0f, 1.0f, 1.0f, 1.0f };
-    const f4 r0 = rcp4(b);
-    const f4 e = fma4(-b, r0, one);
-    return { -b, fma4(e, r0, r0) };
-}
+
 template <bool MAY_BE_ZERO = true>
 static __device__ __forceinline__ f4 divide_by4(const SharedDenominator4 &d, f4 a)
 {
@@ -1036,14 +1037,14 @@ static __device__ __forceinline__ void h2n_quad(f4 px, f4 up, f4 left, float pdx
     const f4 vdx = { pdx, pdx, pdx, pdx }, vdy = { pdy, pdy, pdy, pdy }, half = { 0.5f, 0.5f, 0.5f, 0.5f };
     const f4 zero = { 0.0f, 0.0f, 0.0f, 0.0f };
     const f4 q1 = vdx * vdx + tz0 * tz0, q2 = vdy * vdy + bz0 * bz0;
-    const SharedDenominator4 d1 = shared_denominator4(sqrt_normal4(q1)), d2 = shared_denominator4(sqrt_normal4(q2));
+    const SharedDenominator4 d1 = sqrt_denominator4(q1), d2 = sqrt_denominator4(q2);
     const f4 tx = divide_by4<false>(d1, vdx), tz = divide_by4(d1, tz0);
     const f4 by = divide_by4<false>(d2, vdy), bz = divide_by4(d2, bz0);
     const f4 ty = zero, bx = zero;  // 0 / n
     const f4 cx = ty * bz - tz * by;
     const f4 cy = tz * bx - tx * bz;
     const f4 cz = tx * by - ty * bx;
-    const SharedDenominator4 d3 = shared_denominator4(sqrt_normal4((cx * cx + cy * cy) + cz * cz));
+    const SharedDenominator4 d3 = sqrt_denominator4((cx * cx + cy * cy) + cz * cz);
     const f4 nx = divide_by4(d3, cx), ny = divide_by4(d3, cy), nz = divide_by4<false>(d3, cz);
     r = nx * half + half;
     g = ny * half + half;

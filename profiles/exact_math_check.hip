@@ -77,6 +77,38 @@ __global__ void check_div(uint64_t n, int ea_lo, int ea_hi, int eb_lo, int eb_hi
     }
 }
 
+// The vectorised kernel's variant: the reciprocal of n = sqrt_normal(x) seeded by rsq(x) instead of rcp(n).
+static __device__ __forceinline__ SharedDenominator sqrt_denominator(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y;
+    const float h0 = y * 0.5f;
+    const float e = __builtin_fmaf(-h0, s0, 0.5f);
+    const float h = __builtin_fmaf(h0, e, h0);
+    const float s = __builtin_fmaf(s0, e, s0);
+    const float d = __builtin_fmaf(-s, s, x);
+    const float n = __builtin_fmaf(d, h, s);
+    const float er = __builtin_fmaf(-n, y, 1.0f);
+    return { -n, __builtin_fmaf(er, y, y) };
+}
+
+// a: sign, exponent in [ea_lo, ea_hi]; x: positive, exponent in [ex_lo, ex_hi]; checks a / sqrtf(x)
+__global__ void check_div_sqrt(uint64_t n, int ea_lo, int ea_hi, int ex_lo, int ex_hi, uint64_t seed, unsigned long long *bad,
+                               uint32_t *first_bad)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = splitmix(seed + i), r2 = splitmix(r);
+        const uint32_t ea = (uint32_t)(ea_lo + (int)((r >> 40) % (uint64_t)(ea_hi - ea_lo + 1)) + 127);
+        const uint32_t ex = (uint32_t)(ex_lo + (int)((r2 >> 40) % (uint64_t)(ex_hi - ex_lo + 1)) + 127);
+        const float a = __uint_as_float(((uint32_t)(r & 1) << 31) | (ea << 23) | ((uint32_t)(r >> 1) & 0x7FFFFFu));
+        const float x = __uint_as_float((ex << 23) | ((uint32_t)(r2 >> 1) & 0x7FFFFFu));
+        const float q1 = divide_by(sqrt_denominator(x), a), q2 = a / sqrtf(x);
+        if (__float_as_uint(q1) != __float_as_uint(q2)) {
+            if (atomicAdd(bad, 1ull) == 0) { first_bad[0] = __float_as_uint(a); first_bad[1] = __float_as_uint(x); }
+        }
+    }
+}
+
 int main()
 {
     unsigned long long *bad;
@@ -107,6 +139,20 @@ int main()
         check_div<<<8192, 256>>>(n, rg.ea_lo, rg.ea_hi, rg.eb_lo, rg.eb_hi, 0x5EED0000ull + (uint64_t)rg.ea_lo * 131, bad, first);
         fetch();
         std::printf("divide_by vs a / b, %s: %llu pairs, %llu mismatches (first a=0x%08x b=0x%08x)\n", rg.what,
+                    (unsigned long long)n, hbad, hfirst[0], hfirst[1]);
+        rc |= hbad != 0;
+    }
+    struct RangeS { const char *what; int ea_lo, ea_hi, ex_lo, ex_hi; } sranges[] = {
+        { "pdx, tz0 / sqrt(q)  (a in [2^-40, 2^7], q in [2^-32, 2^15])", -40, 7, -32, 15 },
+        { "cross / sqrt(|cross|^2) (a in [2^-90, 2^0], x in [2^-94, 2^2])", -90, 0, -94, 2 },
+        { "quotients near 1 (a in [2^-3, 2^3], x in [2^-6, 2^6])", -3, 3, -6, 6 },
+    };
+    for (auto &rg : sranges) {
+        reset();
+        const uint64_t n = 1ull << 34;
+        check_div_sqrt<<<8192, 256>>>(n, rg.ea_lo, rg.ea_hi, rg.ex_lo, rg.ex_hi, 0x5EED1000ull + (uint64_t)rg.ea_lo * 131, bad, first);
+        fetch();
+        std::printf("divide_by(sqrt_denominator(x)) vs a / sqrtf(x), %s: %llu pairs, %llu mismatches (first a=0x%08x x=0x%08x)\n", rg.what,
                     (unsigned long long)n, hbad, hfirst[0], hfirst[1]);
         rc |= hbad != 0;
     }
