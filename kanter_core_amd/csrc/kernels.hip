@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void resize_chain_kernel(const ChainProgram P,
     // the expensive part, see chain_run); rows past the tile repeat its last row and are not stored.
     // With one resident input, its quads for trip i + 1 are requested before trip i is computed (the
     // first before the vertical pass): a wave then never waits for loads queued behind its own stores.
-    constexpr int RU = KC_FUSED_RU;
+    constexpr int RU = 4;  // 2 rows per trip: 89.4 us, 1 row: 95.6 us, 4 rows: 83.5 us on config #2 (profiles/r02_fused_ru_ab.txt)
     constexpr bool AHEAD = K <= 2;  // 16 more registers per resident input: not worth the occupancy beyond one
     f4 nxt[KM][RU];
     auto request = [&](uint32_t ty0) {
@@ -964,10 +964,6 @@ static __device__ __forceinline__ void h2n_px(float px, float up, float left, fl
 // Element by element these are exactly the operations of h2n_px's `tame` branch (same instructions, same order);
 // a quad with any pixel outside that range goes through h2n_px pixel by pixel.
 static __device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
-static __device__ __forceinline__ f4 rcp4(f4 x)
-{
-    return f4{ __builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y), __builtin_amdgcn_rcpf(x.z), __builtin_amdgcn_rcpf(x.w) };
-}
 static __device__ __forceinline__ f4 rsq4(f4 x)
 {
     return f4{ __builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y), __builtin_amdgcn_rsqf(x.z), __builtin_amdgcn_rsqf(x.w) };
