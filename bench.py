@@ -13,10 +13,10 @@ resident in HBM.  Rank 0 prints ONE JSON line.
 Default workload:
     N = 1   chain32: the headline.  One launch per step (the 32 nodes are one fused chain); from the third
             evaluation on it is the run-time specialised kernel (csrc/specialize.cpp; the warm-up waits for the compile).
-    N > 1   fanin: BASELINE config #4 -- 8 independent 16-node subgraphs + a 7-node Mix(Add) tree as ONE graph that
-            the library's partitioner (kc_live_graph_partition) spreads over the ranks; branch results go to the home
-            rank as grouped RCCL send/recv of the planes, the join runs there.  "scaling": "strong" (fixed total work);
-            per-rank host compute / exchange times are in "per_rank".  Compare with --gpus 1 --workload fanin.
+    N > 1   chain32_rows --size 8192: BASELINE config #3 -- the same 32-node graph on 8192x8192, every rank evaluating its
+            row band of the result through the library's band path (kc_live_graph_evaluate_band, csrc/bands.cpp) and
+            holding only those rows of the inputs.  A pointwise graph needs no halo and no exchange: "scaling": "strong"
+            (fixed total work), time = max over ranks.
 
 Other workloads (parity-tested configs of BASELINE.json, reported in DESIGN.md):
     --workload mix1           config #1: one Mix(Add) node, two 4096^2 f32x4 inputs
@@ -24,7 +24,10 @@ Other workloads (parity-tested configs of BASELINE.json, reported in DESIGN.md):
     --workload chain32 --size 8192   config #3 at its full size (with N > 1: an independent graph per GPU, weak scaling)
     --workload chain32_rows --size 8192   config #3 split by row bands over the ranks through the library's band path
                               (kc_live_graph_evaluate_band; strong scaling, no exchange)
-    --workload fanin          config #4 (any N, also N = 1)
+    --workload fanin          config #4 (any N, also N = 1): 8 independent 16-node subgraphs + a 7-node Mix(Add) tree as ONE
+                              graph that the library's partitioner (kc_live_graph_partition) spreads over the ranks; branch
+                              results go to the home rank as grouped RCCL send/recv of the planes, the join runs there;
+                              per-rank host compute / exchange times in "per_rank"
 Every workload run with N = 1 also carries a "parity" object: the timed graph's result against the oracle.
 """
 import argparse
@@ -73,9 +76,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=None, choices=["chain32", "chain32_rows", "mix1", "resize_blend", "fanin"],
-                    help="default: chain32 (the headline) on one GPU, fanin (BASELINE config #4, partitioned by the library) on several")
+                    help="default: chain32 at 4096^2 (the headline) on one GPU; on several, chain32_rows at 8192^2 = BASELINE "
+                         "config #3, the 32-node graph split by row bands through the library's band path")
     ap.add_argument("--policy", default="spread", choices=["spread", "auto"], help="fanin: placement policy of the partitioner")
-    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--size", type=int, default=None, help="default 4096; 8192 for the multi-GPU default workload")
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the unfused and PCIe-inclusive side measurements")
@@ -83,7 +87,11 @@ def main():
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N > 1 control flow on one GPU")
     args = ap.parse_args()
     if args.workload is None:
-        args.workload = "chain32" if args.gpus == 1 else "fanin"
+        args.workload = "chain32" if args.gpus == 1 else "chain32_rows"
+        if args.size is None and args.gpus > 1:
+            args.size = 8192
+    if args.size is None:
+        args.size = 4096
 
     import numpy as np
     import torch
@@ -105,7 +113,7 @@ def main():
 
     import kanter_core_amd as kc
     from kanter_core_amd import multi_gpu
-    from util import SEED_A, SEED_B, splitmix_plane
+    from util import SEED_A, SEED_B, splitmix_plane, splitmix_rows
 
     kc.init(device_index)  # raises (no CPU fallback) when the HIP library or the GPU is missing
     # One explicit (non-default) HIP stream shared by torch (events, RCCL ordering) and the library.
@@ -131,7 +139,7 @@ def main():
         y0, y1 = multi_gpu.row_bands(S, world)[rank]
         rows = y1 - y0
         band = (y0, y1)
-        full = lambda seed: [splitmix_plane(seed, c, S, S)[y0:y1].copy() for c in range(4)]  # noqa: E731
+        full = lambda seed: [splitmix_rows(seed, c, S, S, y0, y1) for c in range(4)]  # noqa: E731
         host_a, host_b = full(SEED_A), full(SEED_B)
         args.workload = "chain32"
         band_note = " (row band %d:%d of %d, rank %d/%d)" % (y0, y1, S, rank, world)
@@ -372,7 +380,9 @@ def main():
         "config": {
             "workload": desc, "graph_nodes": N if args.workload == "chain32" else None, "width": S, "height": S,
             "channels": 4, "use_cache": False,
-            "parallelism": ("independent graph per GPU" if args.workload != "fanin" else "branches placed by the library's partitioner + RCCL send/recv to the home rank")
+            "parallelism": (("row bands of one graph through kc_live_graph_evaluate_band, no exchange" if band is not None else
+                             "independent graph per GPU") if args.workload != "fanin"
+                            else "branches placed by the library's partitioner + RCCL send/recv to the home rank")
             if world > 1 else "single GPU",
         },
         "roofline": {

@@ -16,6 +16,17 @@ def splitmix_plane(seed, channel, h, w):
     return ((z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(h, w)
 
 
+def splitmix_rows(seed, channel, h, w, y0, y1):
+    """Rows [y0, y1) of splitmix_plane(seed, channel, h, w) without generating the rest."""
+    idx = (np.uint64(channel) * np.uint64(h) * np.uint64(w)) + np.uint64(y0) * np.uint64(w) + np.arange((y1 - y0) * w, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(y1 - y0, w)
+
+
 def synthetic_rgba(seed, h, w):
     return [splitmix_plane(seed, c, h, w) for c in range(4)]
 
