@@ -5,7 +5,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/rk
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for c in "512 4096 Triangle" "512 4096 Lanczos3" "2048 4096 Triangle" "1000 4096 CatmullRom" "4096 512 Triangle" "4096 2048 Triangle" "4096 1024 Lanczos3" "4096 3000 Triangle"; do
+for c in "512 4096 Triangle" "512 4096 Lanczos3" "2048 4096 Triangle" "1000 4096 CatmullRom" "4096 512 Triangle" "4096 2048 Triangle" "4096 1024 Lanczos3" "4096 3000 Triangle" "4096 1365 CatmullRom" "3000 700 Gaussian"; do
   tag=$(echo $c | tr ' ' '_')
   timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- python3 $GRAFT_REPO_ROOT/profiles/resize_one.py $c 30 > $OUT/$tag.log 2>&1
   f=$(find $OUT/$tag -name "*kernel_stats.csv" | head -1)
