@@ -97,6 +97,9 @@ try {
     Context &c = ctx();
     Lock lk(c.mu);
     if (!c.inited) return KC_OK;
+#ifdef KC_HOST_PROFILE
+    prof_report();
+#endif
     (void)hipStreamSynchronize(c.stream);
     specialize_shutdown();
     pool_trim();

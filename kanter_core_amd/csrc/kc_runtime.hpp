@@ -132,6 +132,21 @@ void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what);  // records the message, returns KC_ERR_HIP
 int need_init();                               // KC_OK or KC_ERR_NO_DEVICE
 
+// Host-side phase timers for tuning (build with KC_HOST_PROFILE=1 python -m kanter_core_amd.build --force): each
+// KC_PROF("name") scope adds its TSC cycles to a named counter, printed at kc_shutdown.  Compiled out otherwise.
+#ifdef KC_HOST_PROFILE
+struct ProfScope {
+    const char *name;
+    unsigned long long t0;
+    explicit ProfScope(const char *n) : name(n), t0(__builtin_ia32_rdtsc()) {}
+    ~ProfScope();
+};
+void prof_report();
+#define KC_PROF(name) kc::ProfScope _kc_prof_scope(name)
+#else
+#define KC_PROF(name) (void)0
+#endif
+
 #define KC_HIP(call)                                           \
     do {                                                       \
         hipError_t _e = (call);                                \

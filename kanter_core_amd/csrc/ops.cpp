@@ -186,6 +186,7 @@ int calculate_size(int policy, const kc_size *sizes, int n, int slot_index, kc_s
 // mix::process, src/node/mix.rs:51-134.
 int mix_process(kc_image *left_in, kc_image *right_in, int mix_type, kc_image **out)
 {
+    KC_PROF("mix_process");
     *out = nullptr;
     kc_image *left = nullptr, *right = nullptr;
     if (left_in) {

@@ -490,6 +490,7 @@ static int resize_plane_uncached(kc_plane *src, kc_size size, int filter, kc_pla
 // aliased planes, e.g. Gray->Rgba [p, p, p, ones], are resampled once and re-aliased).
 int resize_image(kc_image *src, kc_size size, int filter, kc_image **out)
 {
+    KC_PROF("resize_image");
     if (size.width == 0 || size.height == 0) {
         set_error("resize to zero extent");
         return KC_ERR_INVALID_ARG;

@@ -1,6 +1,7 @@
 // Context, HBM plane pool, planes, images and the lazy pointwise-chain machinery.
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 
 #include <algorithm>
@@ -21,6 +22,26 @@ Context &ctx()
 
 void set_error(const std::string &msg) { g_last_error = msg; }
 const std::string &last_error() { return g_last_error; }
+
+#ifdef KC_HOST_PROFILE
+static std::map<std::string, std::pair<unsigned long long, unsigned long long>> &prof_table()
+{
+    static std::map<std::string, std::pair<unsigned long long, unsigned long long>> t;
+    return t;
+}
+ProfScope::~ProfScope()
+{
+    auto &e = prof_table()[name];
+    e.first += __builtin_ia32_rdtsc() - t0;
+    e.second++;
+}
+void prof_report()
+{
+    for (auto &kv : prof_table())
+        std::fprintf(stderr, "KC_PROF %-28s calls %9llu  cycles %14llu  per call %9.0f\n", kv.first.c_str(), kv.second.second,
+                     kv.second.first, (double)kv.second.first / (double)kv.second.second);
+}
+#endif
 
 int hip_fail(hipError_t e, const char *what)
 {
@@ -213,6 +234,7 @@ static int chain_distinct_inputs(const Chain &ch)
 // Builds p->chain (start + steps in order) from the links; planes forced meanwhile end the walk.
 static void chain_flatten(kc_plane *p)
 {
+    KC_PROF("chain_flatten");
     if (p->chain) return;
     Chain *c = new Chain();
     kc_plane *q = p;
@@ -270,6 +292,7 @@ static int input_index(std::vector<const kc_plane *> &ins, const kc_plane *p)
 // chain_prepare) takes slot KM and is recorded in bc.sampled[b].
 static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
 {
+    KC_PROF("chain_fill");
     const Chain &ch = *p->chain;
     ChainProgram &P = bc.prog;
     std::vector<const kc_plane *> ins;
@@ -374,6 +397,7 @@ static int chain_prepare(kc_plane *p)
 
 static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 {
+    KC_PROF("chain_launch");
     Context &c = ctx();
     ChainProgram &P = bc.prog;
     const kc_plane *p0 = planes[0];
@@ -456,6 +480,7 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 
 int planes_force(kc_plane *const *planes, int n)
 {
+    KC_PROF("planes_force");
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
     std::vector<kc_plane *> todo;
     KC_TRY(resize_force_many(planes, n));
@@ -598,6 +623,7 @@ int planes_mix_prepare(kc_plane *const *ls, kc_plane *const *rs, int n)
 
 int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
 {
+    KC_PROF("plane_mix");
     if (mix < KC_MIX_ADD || mix > KC_MIX_POW) {
         set_error("invalid MixType");
         return KC_ERR_INVALID_ARG;
