@@ -154,6 +154,58 @@ int main(void)
     for (size_t i = 0; i < n; ++i) ones[i] = 1.0f;
     kco_mix_plane(1, ones, gray, want, n);
     fails += (is_rgba != 0) + same(gg[0], want, n, "graph: invert of a product");
+    /* round 2: the multi-GPU plan of this graph (host only), row bands of its result, the specialiser's knobs -- from C */
+    {
+        kc_partition *plan;
+        CHECK(kc_live_graph_partition(lg, no, 4, KC_PARTITION_SPREAD, &plan));
+        int world = 0, home = -1, levels = 0;
+        CHECK(kc_partition_info(plan, &world, &home, &levels));
+        uint32_t n_nodes = 0, n_xfer = 0;
+        CHECK(kc_partition_nodes(plan, NULL, 0, &n_nodes));
+        CHECK(kc_partition_transfers(plan, NULL, 0, &n_xfer));
+        kc_placement pl[16];
+        CHECK(kc_partition_nodes(plan, pl, 16, &n_nodes));
+        int replicated = 0, sources = 0;
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            replicated += pl[i].kind == KC_KIND_REPLICATED && pl[i].rank == -1;
+            sources += pl[i].kind == KC_KIND_SOURCE;
+        }
+        /* one chain, nothing to cut: 6 nodes, the Value replicated, both embeds sources, no transfer */
+        if (world != 4 || home != 0 || n_nodes != 6 || n_xfer != 0 || replicated != 1 || sources != 2) {
+            fails += 1;
+            fprintf(stderr, "partition: world %d home %d nodes %u transfers %u replicated %d sources %d\n", world, home, n_nodes, n_xfer, replicated, sources);
+        }
+        CHECK(kc_partition_free(plan));
+
+        kc_band_rows need[4];
+        uint32_t n_need = 0;
+        CHECK(kc_live_graph_band_source_rows(lg, no, 40, 80, need, 4, &n_need));
+        for (uint32_t i = 0; i < n_need; ++i)
+            if (need[i].y0 != 40 || need[i].y1 != 80 || need[i].width != W || need[i].height != H) fails += 1, fprintf(stderr, "band rows of node %u\n", need[i].node_id);
+        if (n_need != 2) fails += 1, fprintf(stderr, "expected the two embedded sources, got %u\n", n_need);
+        kc_image *band;
+        CHECK(kc_live_graph_evaluate_band(lg, no, 0, 40, 80, &band));
+        kc_size bs;
+        CHECK(kc_image_size(band, &bs));
+        float *gb[1];
+        download(band, 1, gb, (size_t)W * 40);
+        fails += (bs.width != W || bs.height != 40) + same(gb[0], gg[0] + (size_t)40 * W, (size_t)W * 40, "rows 40..80 of the graph's result");
+        CHECK(kc_image_release(band));
+
+        CHECK(kc_set_specialize(2, 0)); /* compile at first sight: the next evaluation of this chain uses the generated kernel */
+        CHECK(kc_live_graph_connect(lg, na, nm, 0, 0));
+        CHECK(kc_live_graph_await_clean(lg, no));
+        kc_image *res2;
+        CHECK(kc_live_graph_slot_data(lg, no, 0, &res2));
+        float *g2[1];
+        download(res2, 1, g2, n);
+        uint64_t compiled = 0, failed = 0, spec_launches = 0, pending = 0;
+        CHECK(kc_specialize_stats(&compiled, &failed, &spec_launches, &pending));
+        fails += same(g2[0], want, n, "specialised kernel") + (failed != 0) + (spec_launches == 0);
+        CHECK(kc_image_release(res2));
+        CHECK(kc_set_specialize(1, 2));
+    }
+
     /* an error path: an unknown node id */
     if (kc_live_graph_await_clean(lg, 12345) != KC_ERR_INVALID_NODE_ID) fails += 1, fprintf(stderr, "expected InvalidNodeId\n");
 
