@@ -169,3 +169,32 @@ pub(crate) fn resize_buffers(slot_datas: &[Arc<SlotData>], edges: &[Edge], polic
                                      p, pslot, psize, filter as i32, outs.as_mut_ptr()) })?;
     Ok(slot_datas.iter().zip(outs).map(|(sd, o)| Arc::new(SlotData::new(sd.node_id, sd.slot_id, wrap(o)))).collect())
 }
+
+// ------------------------------------------------------------------------------------------------
+// Several GPUs (one process per GPU; round 2).  The reference has no such layer; these are the two
+// calls a Rust host adds around `LiveGraph` (see INTEGRATION.md section 6 for the exchange loop).
+// ------------------------------------------------------------------------------------------------
+
+/// Which rank evaluates which ancestor of `root`, and which slots cross a rank boundary -- the same
+/// answer on every rank, derived from the graph alone (kc_live_graph_partition, csrc/partition.cpp).
+pub fn partition(lg: *mut KcLiveGraph, root: NodeId, world: i32, spread: bool) -> Result<(Vec<KcPlacement>, Vec<KcTransfer>)> {
+    let mut plan = ptr::null_mut();
+    check(unsafe { kc_live_graph_partition(lg, root.0, world, if spread { 1 } else { 0 }, &mut plan) })?;
+    let (mut n, mut t) = (0u32, 0u32);
+    check(unsafe { kc_partition_nodes(plan, ptr::null_mut(), 0, &mut n) })?;
+    check(unsafe { kc_partition_transfers(plan, ptr::null_mut(), 0, &mut t) })?;
+    let mut nodes = vec![KcPlacement { node_id: 0, rank: 0, component: 0, kind: 0 }; n as usize];
+    let mut xfers = vec![KcTransfer { node_id: 0, slot_id: 0, src_rank: 0, dst_rank: 0, level: 0 }; t as usize];
+    check(unsafe { kc_partition_nodes(plan, nodes.as_mut_ptr(), n, &mut n) })?;
+    check(unsafe { kc_partition_transfers(plan, xfers.as_mut_ptr(), t, &mut t) })?;
+    unsafe { kc_partition_free(plan) };
+    Ok((nodes, xfers))
+}
+
+/// Rows [y0, y1) of `node`'s slot, bit-identical to those rows of the whole-image evaluation
+/// (kc_live_graph_evaluate_band, csrc/bands.cpp): every rank takes its own band of the result.
+pub fn evaluate_band(lg: *mut KcLiveGraph, node: NodeId, slot: SlotId, y0: i32, y1: i32) -> Result<SlotImage> {
+    let mut out = ptr::null_mut();
+    check(unsafe { kc_live_graph_evaluate_band(lg, node.0, slot.0, y0, y1, &mut out) })?;
+    Ok(wrap(out))
+}
