@@ -88,6 +88,9 @@ try {
         if (v >= 0 && v <= 2) specialize_set_mode(v, 0);
     }
     c.inited = true;
+#ifdef KC_HOST_SAMPLE
+    sampler_start();
+#endif
     return KC_OK;
 }
 KC_CATCH
@@ -99,6 +102,9 @@ try {
     if (!c.inited) return KC_OK;
 #ifdef KC_HOST_PROFILE
     prof_report();
+#endif
+#ifdef KC_HOST_SAMPLE
+    sampler_report();
 #endif
     (void)hipStreamSynchronize(c.stream);
     specialize_shutdown();
@@ -267,6 +273,7 @@ KC_CATCH
 // ---------------------------------------------------------------- planes
 int kc_plane_alloc(uint32_t w, uint32_t h, kc_plane **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(out);
     return plane_new_mem(w, h, out);
 }
@@ -274,6 +281,7 @@ KC_CATCH
 
 int kc_plane_const(uint32_t w, uint32_t h, float v, kc_plane **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(out && w > 0 && h > 0);
     *out = plane_new_const(w, h, v);
     return KC_OK;
@@ -282,6 +290,7 @@ KC_CATCH
 
 int kc_plane_wrap(void *dptr, uint32_t w, uint32_t h, size_t pitch, kc_plane **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_TRY(need_init());
     KC_ARG(out && dptr && w > 0 && h > 0);
     // kernels move 16 bytes per lane: rows must start 16-byte aligned and be readable in whole
@@ -304,6 +313,7 @@ KC_CATCH
 
 int kc_plane_retain(kc_plane *p)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(p);
     plane_retain(p);
     return KC_OK;
@@ -339,6 +349,7 @@ KC_CATCH
 
 int kc_plane_materialize(kc_plane *p)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(p);
     return plane_materialize(p);
 }
@@ -389,6 +400,7 @@ KC_CATCH
 // ---------------------------------------------------------------- images
 int kc_image_gray(kc_plane *p, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(p && out);
     *out = image_new(1, &p);
     return KC_OK;
@@ -397,6 +409,7 @@ KC_CATCH
 
 int kc_image_rgba(kc_plane *const planes[4], kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(planes && out && planes[0] && planes[1] && planes[2] && planes[3]);
     for (int i = 1; i < 4; ++i) KC_ARG(planes[i]->w == planes[0]->w && planes[i]->h == planes[0]->h);
     *out = image_new(4, planes);
@@ -406,6 +419,7 @@ KC_CATCH
 
 int kc_image_retain(kc_image *img)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(img);
     image_retain(img);
     return KC_OK;
@@ -439,6 +453,7 @@ KC_CATCH
 
 int kc_image_plane(const kc_image *img, int channel, kc_plane **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(img && out && channel >= 0 && channel < img->n);
     *out = img->planes[channel];
     plane_retain(*out);
@@ -448,6 +463,7 @@ KC_CATCH
 
 int kc_image_from_value(kc_size size, float v, int rgba, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(out);
     return image_from_value(size, v, rgba != 0, out);
 }
@@ -455,6 +471,7 @@ KC_CATCH
 
 int kc_image_as_type(const kc_image *img, int rgba, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(img && out);
     return image_as_type(const_cast<kc_image *>(img), rgba != 0, out);
 }
@@ -472,6 +489,7 @@ KC_CATCH
 
 int kc_image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(out);
     return image_from_u8(host, w, h, channels, out);  // synchronises: host buffer may be reused on return
 }
@@ -479,6 +497,7 @@ KC_CATCH
 
 int kc_image_to_u8(kc_image *img, int srgb, uint8_t *host)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(img && host);
     return image_to_u8(img, srgb != 0, host);
 }
@@ -486,6 +505,7 @@ KC_CATCH
 
 int kc_image_from_f32(const float *const host_planes[], int n, uint32_t w, uint32_t h, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(host_planes && out && (n == 1 || n == 4));
     kc_plane *p[4] = { nullptr, nullptr, nullptr, nullptr };
     int s = KC_OK;
@@ -511,6 +531,7 @@ KC_CATCH
 
 int kc_image_read_png(const char *path, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(path && out);
     std::vector<uint8_t> px;
     uint32_t w = 0, h = 0;
@@ -522,6 +543,7 @@ KC_CATCH
 
 int kc_image_write_png(kc_image *img, const char *path)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(img && path);
     std::vector<uint8_t> px((size_t)img->w() * img->h() * 4);
     KC_TRY(image_to_u8(img, false, px.data()));
@@ -539,6 +561,7 @@ KC_CATCH
 
 int kc_resize_image(kc_image *src, kc_size size, int filter, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(src && out);
     return resize_image(src, size, filter, out);
 }
@@ -547,6 +570,7 @@ KC_CATCH
 int kc_resize_buffers(kc_image *const images[], const kc_edge keys[], int n, const kc_edge *edges_sorted, int n_edges,
                       int policy, uint32_t policy_slot, kc_size policy_size, int filter, kc_image *out[])
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(n >= 0 && (n == 0 || (images && keys && out)));
     if (n == 0) return KC_OK;  // shared.rs:147-149
     std::vector<kc_size> sizes;
@@ -587,6 +611,7 @@ KC_CATCH
 
 int kc_mix_process(kc_image *left, kc_image *right, int mix_type, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(out);
     return mix_process(left, right, mix_type, out);
 }
@@ -594,6 +619,7 @@ KC_CATCH
 
 int kc_separate_rgba_process(kc_image *input, kc_image *out[4])
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(out);
     return separate_process(input, out);
 }
@@ -601,6 +627,7 @@ KC_CATCH
 
 int kc_combine_rgba_process(kc_image *const inputs[4], kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(inputs && out);
     return combine_process(inputs, out);
 }
@@ -608,6 +635,7 @@ KC_CATCH
 
 int kc_value_process(float v, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(out);
     return value_process(v, out);
 }
@@ -615,6 +643,7 @@ KC_CATCH
 
 int kc_height_to_normal_process(kc_image *input, kc_image **out)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     KC_ARG(out);
     return height_to_normal_process(input, out);
 }
@@ -864,6 +893,7 @@ KC_CATCH
 
 int kc_tex_pro_free(kc_tex_pro *tp)
 try {
+    Lock api_lock(ctx().mu);  // reference counts are plain integers, see kc_plane::refs
     delete tp;
     return KC_OK;
 }
@@ -1220,6 +1250,7 @@ int kc_live_graph_changed_consume(kc_live_graph *lg, uint32_t *ids, uint32_t cap
 try {
     LG_LOCK(lg);
     std::vector<uint32_t> v(lg->changed.begin(), lg->changed.end());
+    std::sort(v.begin(), v.end());
     if (ids && cap >= v.size()) lg->changed.clear();  // a NULL / short buffer only queries the count
     return copy_ids(v, ids, cap, count);
 }

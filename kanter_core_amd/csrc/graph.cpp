@@ -401,7 +401,7 @@ std::vector<uint32_t> NodeGraph::output_ids() const
 // ------------------------------------------------------------------------------------------
 // process_node, src/node/node_type.rs:213-267 (+ resize_buffers, src/shared.rs:141-216)
 // ------------------------------------------------------------------------------------------
-static void release_all(std::vector<SlotData> &v)
+static void release_all(SlotList &v)
 {
     for (auto &sd : v) image_release(sd.image);
     v.clear();
@@ -429,15 +429,14 @@ static kc_image *pixel_image_rgba(float r, float g, float b, float a)
     return img;
 }
 
-static const SlotData *with_slot(const std::vector<SlotData> &v, uint32_t slot)
+static const SlotData *with_slot(const SlotList &v, uint32_t slot)
 {
     for (auto &sd : v)
         if (sd.slot_id == slot) return &sd;
     return nullptr;
 }
 
-static int process_graph_node(kc_live_graph &parent, const Node &node, const std::vector<SlotData> &slot_datas,
-                              std::vector<SlotData> &out)
+static int process_graph_node(kc_live_graph &parent, const Node &node, const SlotList &slot_datas, SlotList &out)
 {
     // graph::process, src/node/graph.rs:14-51
     if (parent.depth > 32) {
@@ -465,7 +464,7 @@ static int process_graph_node(kc_live_graph &parent, const Node &node, const std
     return KC_OK;
 }
 
-static int dispatch(kc_live_graph &lg, const Node &node, const std::vector<SlotData> &sd, std::vector<SlotData> &out)
+static int dispatch(kc_live_graph &lg, const Node &node, const SlotList &sd, SlotList &out)
 {
     // process_node_internal, src/node/node_type.rs:98-138
     const uint32_t nid = node.node_id;
@@ -578,22 +577,28 @@ static int dispatch(kc_live_graph &lg, const Node &node, const std::vector<SlotD
     return KC_ERR_INVALID_NODE_TYPE;
 }
 
-int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData> &inputs,
-                 const std::vector<kc_edge> &edges, std::vector<SlotData> &out)
+int process_node(kc_live_graph &lg, const Node &node, const SlotList &inputs, const std::vector<kc_edge> &edges,
+                 SlotList &out)
 {
     if (edges.size() != inputs.size()) {
         set_error("process_node: edges / slot data count mismatch");
         return KC_ERR_INVALID_BUFFER_COUNT;
     }
     // node_type.rs:229-231: edges sorted by input slot (slot datas stay in edge insertion order)
-    std::vector<kc_edge> sorted = edges;
-    std::stable_sort(sorted.begin(), sorted.end(), [](const kc_edge &a, const kc_edge &b) { return a.input_slot < b.input_slot; });
+    // (a stable insertion sort: a node has a handful of edges, and std::stable_sort takes a heap buffer)
+    EdgeList sorted(edges.data(), edges.size());
+    for (size_t i = 1; i < sorted.size(); ++i) {
+        const kc_edge e = sorted[i];
+        size_t j = i;
+        for (; j > 0 && sorted[j - 1].input_slot > e.input_slot; --j) sorted[j] = sorted[j - 1];
+        sorted[j] = e;
+    }
 
     // resize_buffers, src/shared.rs:141-216
-    std::vector<SlotData> resized;
+    SlotList resized;
     KC_PROF("process_node_body");
     if (!inputs.empty()) {
-        std::vector<kc_size> sizes;
+        SmallVec<kc_size, 8> sizes;
         for (auto &sd : inputs) sizes.push_back(kc_size{ sd.image->w(), sd.image->h() });
         int slot_index = -1;
         if (node.policy == KC_POLICY_SPECIFIC_SLOT) {
@@ -630,7 +635,7 @@ int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData
         }
     }
     // assign_slot_ids, node_type.rs:250-267
-    std::vector<SlotData> assigned;
+    SlotList assigned;
     for (auto &e : sorted)
         for (auto &sd : resized)
             if (e.output_slot == sd.slot_id && e.output_id == sd.node_id) {
@@ -640,7 +645,8 @@ int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData
             }
     release_all(resized);
 
-    std::vector<SlotData> result;
+    SlotList &result = out;  // empty on entry; stays empty on every error return
+    result.clear();
     int s;
     {
         KC_PROF("dispatch");
@@ -657,7 +663,6 @@ int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData
         release_all(result);
         return KC_ERR_INVALID_BUFFER_COUNT;
     }
-    out = std::move(result);
     return KC_OK;
 }
 
@@ -833,11 +838,13 @@ int kc_live_graph::process_one(uint32_t id)
     KC_PROF("process_one");
     const Node *np = g.find(id);
     if (!np) return KC_ERR_INVALID_NODE_ID;
-    Node node = *np;
+    // Nothing below changes nodes or edges (operators only read them, a Graph node evaluates a copy of its
+    // child graph), so the node and its edge list are used in place.
+    const Node &node = *np;
     node_state[id] = KC_STATE_PROCESSING;
     // engine.rs:213-218: input edges in insertion order; :261-275: one SlotData per edge
-    const std::vector<kc_edge> edges = g.edges_into(id);  // a copy: processing may touch the graph
-    std::vector<SlotData> inputs;
+    const std::vector<kc_edge> &edges = g.edges_into(id);
+    SlotList inputs;
     for (auto &e : edges) {
         const SlotData *sd = find_slot(e.output_id, e.output_slot);
         if (!sd) {
@@ -847,7 +854,7 @@ int kc_live_graph::process_one(uint32_t id)
         }
         inputs.push_back(*sd);
     }
-    std::vector<SlotData> outs;
+    SlotList outs;
     int s = process_node(*this, node, inputs, edges, outs);
     if (s != KC_OK) {
         // engine.rs:111-118 shuts the processor down and panics; here the node goes back to Dirty
@@ -871,11 +878,14 @@ int kc_live_graph::process_one(uint32_t id)
         // engine.rs:58-75: a parent's planes are dropped once every child of it is Clean or Processing
         // (edge lists straight from the index: a parent or child seen twice changes nothing)
         for (auto &pe : edges) {
+            // the scan runs from the newest edge: children are usually evaluated in the order they were connected,
+            // so a child that is still Dirty is found at once
             bool all_done = true;
-            for (auto &ce : g.edges_out_of(pe.output_id)) {
+            const std::vector<kc_edge> &children = g.edges_out_of(pe.output_id);
+            for (size_t i = children.size(); all_done && i-- > 0;) {
                 int st = KC_STATE_DIRTY;
-                (void)state_of(ce.input_id, &st);
-                if (st != KC_STATE_CLEAN && st != KC_STATE_PROCESSING) all_done = false;
+                (void)state_of(children[i].input_id, &st);
+                all_done = st == KC_STATE_CLEAN || st == KC_STATE_PROCESSING;
             }
             if (all_done) remove_nodes_data(pe.output_id);
         }
@@ -887,47 +897,54 @@ int kc_live_graph::ensure_clean(uint32_t root)
 {
     KC_PROF("ensure_clean_total");
     // Parents first (LiveGraph::get_closest_processable, :279-311, collapsed into a depth-first walk).  The
-    // walk keeps its own stack -- a 100 000-node chain must not exhaust the thread's -- and the set of nodes
-    // on it: an edge back into that set is a cycle, which connect() and the JSON reader accept (as the
-    // reference's do) and which can never become Clean.
+    // walk keeps its own stack -- a 100 000-node chain must not exhaust the thread's.  connect() and the JSON
+    // reader accept a cycle (as the reference's do) and a node on one can never become Clean: the stack is a
+    // path of distinct nodes otherwise, so one deeper than the node count has walked round a cycle.
     struct Frame {
         uint32_t id;
-        std::vector<kc_edge> edges;  // a copy: processing may touch the graph
-        size_t next = 0;
-        bool awaiting = false;  // edges[next - 1]'s producer has just been brought up to date
+        const std::vector<kc_edge> *edges;  // the index's list: nothing changes nodes or edges during the walk
+        size_t next;
+        bool awaiting;  // edges[next - 1]'s producer has just been brought up to date
     };
-    std::deque<Frame> stack;
-    std::set<uint32_t> on_stack;
+    std::vector<Frame> stack;
+    stack.reserve(64);
+    const size_t max_depth = g.nodes.size();
     auto enter = [&](uint32_t id) -> int {
         int st;
         KC_TRY(state_of(id, &st));
         if (st == KC_STATE_CLEAN) return KC_OK;
-        if (!on_stack.insert(id).second) {
-            set_error("graph has a cycle through node " + std::to_string(id));
+        if (stack.size() >= max_depth) {
+            std::set<uint32_t> seen;
+            uint32_t twice = id;
+            for (auto &f : stack)
+                if (!seen.insert(f.id).second) {
+                    twice = f.id;
+                    break;
+                }
+            set_error("graph has a cycle through node " + std::to_string(twice));
             return KC_ERR_NODE_PROCESSING;
         }
-        stack.push_back(Frame{ id, g.edges_into(id) });
+        stack.push_back(Frame{ id, &g.edges_into(id), 0, false });
         return KC_OK;
     };
     KC_TRY(enter(root));
     while (!stack.empty()) {
         Frame &f = stack.back();
         if (f.awaiting) {
-            const kc_edge &e = f.edges[f.next - 1];
+            const kc_edge &e = (*f.edges)[f.next - 1];
             f.awaiting = false;
             if (!find_slot(e.output_id, e.output_slot)) {
                 set_error("a parent produced no data for a connected slot");
                 return KC_ERR_NO_SLOT_DATA;
             }
         }
-        if (f.next == f.edges.size()) {
+        if (f.next == f.edges->size()) {
             const uint32_t id = f.id;
             stack.pop_back();
-            on_stack.erase(id);
             KC_TRY(process_one(id));
             continue;
         }
-        const kc_edge e = f.edges[f.next++];
+        const kc_edge e = (*f.edges)[f.next++];
         int pst;
         if (state_of(e.output_id, &pst) != KC_OK) continue;  // parent deleted
         if (pst == KC_STATE_CLEAN && !find_slot(e.output_id, e.output_slot)) {
@@ -971,6 +988,7 @@ int kc_live_graph::update()
             requested.push_back(kv.first);
         }
     }
+    std::sort(requested.begin(), requested.end());  // ascending ids, whatever order the state table iterates in
     for (uint32_t id : requested) {
         if (!g.find(id)) continue;
         KC_TRY(ensure_clean(id));

@@ -1,10 +1,13 @@
 // Host runtime declarations: context, HBM plane pool, planes / images, node operators, graphs.
 #pragma once
 
+#include <cstring>
 #include <deque>
 #include <set>
 #include <tuple>
+#include <type_traits>
 #include <unordered_map>
+#include <unordered_set>
 
 #include "kc_internal.hpp"
 
@@ -16,14 +19,82 @@ struct Chain;
 struct ChainLink;
 }
 
+// Fixed-size objects the evaluator creates and drops by the hundred per evaluation (a plane, a chain link and an
+// image per node and channel) come from free lists: released together when a chain has run, they overflow
+// malloc's small per-thread cache and took its locked fast-bin path -- a third of the host time of a 256 x 256
+// evaluation (profiles/r02_host_samples.txt).  The lists are guarded by Context::mu, which every creator and
+// releaser of these objects holds (see kc_plane::refs); a list keeps at most kMaxFree blocks.  Sanitizer builds
+// use plain new / delete so that they still see every use after free.
+namespace kc {
+#if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__)
+#define KC_NO_OBJECT_POOL 1
+#elif defined(__has_feature)
+#if __has_feature(address_sanitizer) || __has_feature(thread_sanitizer)
+#define KC_NO_OBJECT_POOL 1
+#endif
+#endif
+template <class T> struct Pooled {
+#ifndef KC_NO_OBJECT_POOL
+    struct FreeList {
+        struct Block { Block *next; };
+        static constexpr size_t kMaxFree = 1u << 14;
+        Block *head = nullptr;
+        size_t n = 0;
+        bool closed = false;  // the process is exiting: objects released by later exit handlers go straight to the heap
+        ~FreeList()
+        {
+            closed = true;
+            while (head) {
+                Block *b = head;
+                head = b->next;
+                ::operator delete(b);
+            }
+            n = 0;
+        }
+    };
+    static FreeList &list()
+    {
+        static FreeList fl;
+        return fl;
+    }
+    static void *operator new(size_t bytes)
+    {
+        FreeList &fl = list();
+        if (bytes == sizeof(T) && fl.head) {
+            typename FreeList::Block *b = fl.head;
+            fl.head = b->next;
+            --fl.n;
+            return b;
+        }
+        return ::operator new(bytes < sizeof(typename FreeList::Block) ? sizeof(typename FreeList::Block) : bytes);
+    }
+    static void operator delete(void *q, size_t bytes)
+    {
+        FreeList &fl = list();
+        if (bytes == sizeof(T) && fl.n < FreeList::kMaxFree && !fl.closed) {
+            typename FreeList::Block *b = static_cast<typename FreeList::Block *>(q);
+            b->next = fl.head;
+            fl.head = b;
+            ++fl.n;
+            return;
+        }
+        ::operator delete(q);
+    }
+#endif
+};
+}  // namespace kc
+
 // One channel.  MEM: pitched f32 in HBM.  CONST: broadcast scalar (what the reference holds as
 // vec![v; n]).  LAZY: a pointwise Mix chain that has not been run yet; forcing it launches the
 // fused chain kernel and turns the plane into MEM.  RESIZE: `rz_src` resampled to w x h with
 // `rz_filter`, not run yet: a Mix chain that consumes it resamples inside its own kernel
 // (resize_chain_kernel), anything else forces it through the plain resize kernel.
-struct kc_plane {
+struct kc_plane : kc::Pooled<kc_plane> {
     enum Kind { MEM = 0, CONST = 1, LAZY = 2, RESIZE = 3 };
-    std::atomic<int> refs{ 1 };
+    // Reference counts are plain integers: every C-ABI entry that creates, retains or releases a plane or an
+    // image holds Context::mu (c_api.cpp), as the evaluator always did -- an evaluation touches them some
+    // thirty times per node, and the locked read-modify-writes were a quarter of its host time.
+    int refs = 1;
     uint32_t w = 0, h = 0;
     Kind kind = MEM;
     float *dptr = nullptr;
@@ -39,8 +110,8 @@ struct kc_plane {
 };
 
 // SlotImage, src/slot_image.rs:15-19
-struct kc_image {
-    std::atomic<int> refs{ 1 };
+struct kc_image : kc::Pooled<kc_image> {
+    int refs = 1;  // under Context::mu, like kc_plane::refs
     int n = 0;  // 1 = Gray, 4 = Rgba
     kc_plane *planes[4] = { nullptr, nullptr, nullptr, nullptr };
     bool is_rgba() const { return n == 4; }
@@ -55,7 +126,7 @@ struct ChainStep {
     kc_plane *operand;  // retained; MEM or CONST
 };
 
-struct Chain {
+struct Chain : Pooled<Chain> {
     kc_plane *start = nullptr;  // retained; MEM, CONST or RESIZE
     std::vector<ChainStep> steps;
     ~Chain();
@@ -65,7 +136,7 @@ struct Chain {
 // the same prefix share it (a 64-node linear graph used to copy 3 x 64 x 32 steps per evaluation).
 // The flat Chain is built from the links when the plane is forced; a `prev` that has been forced in
 // the meantime is resident and simply becomes the start.
-struct ChainLink {
+struct ChainLink : Pooled<ChainLink> {
     kc_plane *prev = nullptr;   // retained; the LAZY plane continued, or nullptr
     kc_plane *start = nullptr;  // retained; the chain's first value when prev == nullptr
     ChainStep step{};           // operand retained
@@ -147,6 +218,11 @@ void prof_report();
 #define KC_PROF(name) (void)0
 #endif
 
+#ifdef KC_HOST_SAMPLE
+void sampler_start();   // SIGPROF sampling of the host side, see runtime.cpp
+void sampler_report();
+#endif
+
 #define KC_HIP(call)                                           \
     do {                                                       \
         hipError_t _e = (call);                                \
@@ -165,7 +241,10 @@ int pool_trim();
 
 int plane_new_mem(uint32_t w, uint32_t h, kc_plane **out);
 kc_plane *plane_new_const(uint32_t w, uint32_t h, float v);
-void plane_retain(kc_plane *p);
+inline void plane_retain(kc_plane *p)
+{
+    if (p) ++p->refs;
+}
 void plane_release(kc_plane *p);
 int plane_force(kc_plane *p);                           // LAZY -> MEM (CONST stays CONST)
 int planes_force(kc_plane *const *planes, int n);       // batches chains that share a program
@@ -177,7 +256,10 @@ int planes_mix_prepare(kc_plane *const *ls, kc_plane *const *rs, int n);
 Operand plane_operand(const kc_plane *p);               // MEM or CONST only
 
 kc_image *image_new(int n, kc_plane *const *planes);    // retains the planes
-void image_retain(kc_image *img);
+inline void image_retain(kc_image *img)
+{
+    if (img) ++img->refs;
+}
 void image_release(kc_image *img);
 int image_force(kc_image *img);
 
@@ -312,6 +394,70 @@ struct SlotData {
     kc_image *image;  // retained
 };
 
+// A vector of plain records with room for N of them inside the object: the evaluator builds half a dozen
+// two-or-three-element lists per node (inputs, resized, assigned, results ...) and the heap round trips for
+// them were a measurable part of the ~0.7 us a node costs on the host.
+template <class T, size_t N> class SmallVec {
+    static_assert(std::is_trivially_copyable<T>::value, "SmallVec holds plain records only");
+    T inl_[N];
+    T *p_ = inl_;
+    size_t n_ = 0, cap_ = N;
+
+    void grow(size_t want)
+    {
+        size_t cap = cap_ * 2 > want ? cap_ * 2 : want;
+        T *q = static_cast<T *>(::operator new(cap * sizeof(T)));
+        std::memcpy(static_cast<void *>(q), p_, n_ * sizeof(T));
+        if (p_ != inl_) ::operator delete(p_);
+        p_ = q;
+        cap_ = cap;
+    }
+
+public:
+    SmallVec() = default;
+    SmallVec(const T *first, size_t n) { assign(first, n); }
+    SmallVec(const SmallVec &o) { assign(o.p_, o.n_); }
+    SmallVec &operator=(const SmallVec &o)
+    {
+        if (this != &o) assign(o.p_, o.n_);
+        return *this;
+    }
+    ~SmallVec()
+    {
+        if (p_ != inl_) ::operator delete(p_);
+    }
+    void assign(const T *first, size_t n)
+    {
+        n_ = 0;
+        if (n > cap_) grow(n);
+        if (n) std::memcpy(static_cast<void *>(p_), first, n * sizeof(T));
+        n_ = n;
+    }
+    void push_back(const T &v)
+    {
+        if (n_ == cap_) {
+            const T copy = v;  // v may live in this vector
+            grow(n_ + 1);
+            p_[n_++] = copy;
+            return;
+        }
+        p_[n_++] = v;
+    }
+    void clear() { n_ = 0; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
+    T *begin() { return p_; }
+    T *end() { return p_ + n_; }
+    const T *begin() const { return p_; }
+    const T *end() const { return p_ + n_; }
+};
+using SlotList = SmallVec<SlotData, 8>;
+using EdgeList = SmallVec<kc_edge, 8>;
+
 struct EmbeddedSlotData {
     uint32_t slot_data_id, slot_id;
     kc_image *image;
@@ -333,8 +479,8 @@ struct kc_live_graph {
     std::deque<kc::SlotData> slot_datas;
     std::vector<kc::EmbeddedSlotData> embedded;
     std::vector<kc::SlotData> input_slot_datas;
-    std::map<uint32_t, int> node_state;
-    std::set<uint32_t> changed;
+    std::unordered_map<uint32_t, int> node_state;  // looked up a dozen times per node and evaluation
+    std::unordered_set<uint32_t> changed;  // reported in ascending id order (kc_live_graph_changed_consume)
     bool auto_update = false;
     bool use_cache = false;
     std::string base_dir;
@@ -374,6 +520,6 @@ int band_evaluate(kc_live_graph &lg, uint32_t root, uint32_t slot, int32_t y0, i
 int band_source_rows(kc_live_graph &lg, uint32_t root, int32_t y0, int32_t y1, std::vector<kc_band_rows> &out);
 int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out);
 // process_node, src/node/node_type.rs:213-248: inputs in edge insertion order.
-int process_node(kc_live_graph &lg, const Node &node, const std::vector<SlotData> &inputs,
-                 const std::vector<kc_edge> &edges, std::vector<SlotData> &out);
+int process_node(kc_live_graph &lg, const Node &node, const SlotList &inputs, const std::vector<kc_edge> &edges,
+                 SlotList &out);
 }  // namespace kc

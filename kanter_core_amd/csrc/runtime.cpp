@@ -6,6 +6,14 @@
 
 #include <algorithm>
 
+#ifdef KC_HOST_SAMPLE
+#include <dlfcn.h>
+#include <new>
+#include <signal.h>
+#include <sys/time.h>
+#include <ucontext.h>
+#endif
+
 #include "kc_runtime.hpp"
 
 namespace kc {
@@ -42,6 +50,75 @@ void prof_report()
                      kv.second.first, (double)kv.second.first / (double)kv.second.second);
 }
 #endif
+
+#ifdef KC_HOST_SAMPLE
+// A sampling profile of the host side for tuning builds (KC_HOST_SAMPLE=1 python -m kanter_core_amd.build --force):
+// SIGALRM every 100 us (wall clock: the CPU-time timers tick at 10 ms) records the interrupted PC; kc_shutdown writes "module offset" lines
+// to $KC_SAMPLE_OUT, which profiles/host_samples.py turns into a per-function table with this build's symbols.
+static constexpr size_t kMaxSamples = 1u << 20;
+static void *g_samples[kMaxSamples];
+static std::atomic<size_t> g_n_samples{ 0 };
+static void on_sigprof(int, siginfo_t *, void *uc)
+{
+    const size_t i = g_n_samples.fetch_add(1, std::memory_order_relaxed);
+    if (i < kMaxSamples) g_samples[i] = (void *)((ucontext_t *)uc)->uc_mcontext.gregs[REG_RIP];
+}
+// This library's own heap traffic by request size (the definitions below replace operator new / delete for
+// this library only: hidden visibility binds them locally).
+static std::atomic<unsigned long long> g_new_calls[12];
+void sampler_count_new(size_t bytes)
+{
+    int b = 0;
+    while ((16u << b) < bytes && b < 11) ++b;
+    g_new_calls[b].fetch_add(1, std::memory_order_relaxed);
+}
+void sampler_start()
+{
+    if (!std::getenv("KC_SAMPLE_OUT")) return;
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = on_sigprof;
+    sa.sa_flags = SA_SIGINFO | SA_RESTART;
+    sigaction(SIGALRM, &sa, nullptr);
+    struct itimerval it = { { 0, 100 }, { 0, 100 } };
+    setitimer(ITIMER_REAL, &it, nullptr);
+}
+void sampler_report()
+{
+    const char *path = std::getenv("KC_SAMPLE_OUT");
+    if (!path) return;
+    struct itimerval off = { { 0, 0 }, { 0, 0 } };
+    setitimer(ITIMER_REAL, &off, nullptr);
+    for (int b = 0; b < 12; ++b)
+        if (g_new_calls[b].load()) std::fprintf(stderr, "KC_SAMPLE operator new, <= %5u bytes: %llu calls\n", 16u << b, g_new_calls[b].load());
+    FILE *f = std::fopen(path, "w");
+    if (!f) return;
+    const size_t n = std::min(g_n_samples.load(), kMaxSamples);
+    for (size_t i = 0; i < n; ++i) {
+        Dl_info di;
+        if (dladdr(g_samples[i], &di) && di.dli_fname)
+            std::fprintf(f, "%s %lx %s\n", di.dli_fname, (unsigned long)((char *)g_samples[i] - (char *)di.dli_fbase),
+                         di.dli_sname ? di.dli_sname : "?");
+        else
+            std::fprintf(f, "? %lx ?\n", (unsigned long)g_samples[i]);
+    }
+    std::fclose(f);
+}
+#endif
+
+}  // namespace kc
+#ifdef KC_HOST_SAMPLE
+void *operator new(size_t bytes)
+{
+    kc::sampler_count_new(bytes);
+    void *p = std::malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void operator delete(void *p) noexcept { std::free(p); }
+void operator delete(void *p, size_t) noexcept { std::free(p); }
+#endif
+namespace kc {
 
 int hip_fail(hipError_t e, const char *what)
 {
@@ -157,15 +234,10 @@ kc_plane *plane_new_const(uint32_t w, uint32_t h, float v)
     return p;
 }
 
-void plane_retain(kc_plane *p)
-{
-    if (p) p->refs.fetch_add(1, std::memory_order_relaxed);
-}
-
 void plane_release(kc_plane *p)
 {
     if (!p) return;
-    if (p->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+    if (--p->refs == 0) {
         if (p->chain) delete p->chain;
         if (p->link) delete p->link;
         if (p->rz_src) plane_release(p->rz_src);
@@ -190,13 +262,13 @@ ChainLink::~ChainLink()
     kc_plane *q = prev;
     prev = nullptr;
     while (q) {
-        if (q->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) break;  // still referenced elsewhere
+        if (--q->refs != 0) break;  // still referenced elsewhere
         kc_plane *next = nullptr;
         if (q->link) {
             next = q->link->prev;
             q->link->prev = nullptr;
         }
-        q->refs.store(1, std::memory_order_relaxed);
+        q->refs = 1;
         plane_release(q);  // frees q (its link no longer has a prev)
         q = next;
     }
@@ -237,6 +309,7 @@ static void chain_flatten(kc_plane *p)
     KC_PROF("chain_flatten");
     if (p->chain) return;
     Chain *c = new Chain();
+    c->steps.reserve(p->link->length);
     kc_plane *q = p;
     for (;;) {
         ChainLink *L = q->link;
@@ -590,6 +663,8 @@ static uint8_t code_for(int mix, bool acc_is_left)
 // Would continuing `acc` with a step on `opnd` exceed one program (steps or distinct input planes)?
 static bool chain_full_with(const kc_plane *acc, const kc_plane *opnd)
 {
+    if (acc->link->length >= (uint32_t)KC_CHAIN_MAX_OPS) return true;
+    if (acc->link->n_in < KC_CHAIN_MAX_IN) return false;  // one more operand adds at most one input
     ChainLink probe;
     probe.n_in = acc->link->n_in;
     for (int i = 0; i < probe.n_in && i <= KC_CHAIN_MAX_IN; ++i) probe.ins[i] = acc->link->ins[i];
@@ -705,15 +780,10 @@ kc_image *image_new(int n, kc_plane *const *planes)
     return img;
 }
 
-void image_retain(kc_image *img)
-{
-    if (img) img->refs.fetch_add(1, std::memory_order_relaxed);
-}
-
 void image_release(kc_image *img)
 {
     if (!img) return;
-    if (img->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+    if (--img->refs == 0) {
         for (int i = 0; i < img->n; ++i) plane_release(img->planes[i]);
         delete img;
     }

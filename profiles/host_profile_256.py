@@ -14,7 +14,7 @@ first,last=bench.add_chain(kc,lg,na,nb,32)
 for _ in range(50):
     lg.connect(na,first,0,0); lg.await_clean(last)
 kc.specialize_wait()
-n=5000
+n=int(os.environ.get('KC_EVALS','5000'))
 t0=time.perf_counter()
 for _ in range(n):
     lg.connect(na,first,0,0); lg.await_clean(last)
