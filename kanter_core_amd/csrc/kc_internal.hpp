@@ -56,6 +56,11 @@ inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t v_stride,
     if (h_stride > KC_RESIZE_REG_TAPS) n += 2u * tile_w + (size_t)tile_w * h_stride;
     return n * sizeof(float);
 }
+// resize_down_kernel: swizzled intermediate rows + the tile's horizontal taps at an odd pitch
+inline size_t resize_down_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t tile_w, uint32_t h_stride)
+{
+    return ((size_t)tile_h * ((size_t)ncp + (ncp >> 5) + 1u) + 2u * tile_w + (size_t)tile_w * (h_stride | 1u)) * sizeof(float);
+}
 // Up to 4 planes of equal size (the planes of one image) resampled by one launch, blockIdx.z = plane.
 struct ResizePlanes {
     const float *src[4];
@@ -64,6 +69,8 @@ struct ResizePlanes {
 };
 hipError_t launch_resize_lds(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
                              uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);
+hipError_t launch_resize_down(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,
+                              uint32_t tile_h, uint32_t ncp, hipStream_t s);
 // Fused resample + chain: input slot n_in - 1 of the program is produced by the resampler.
 hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);

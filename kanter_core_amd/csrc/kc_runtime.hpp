@@ -177,7 +177,7 @@ struct Context {
     bool fusion = true;
     int max_blocks = 4096;
     int chain_unroll = 0;  // float4 per thread per decode in the chain kernel; 0 = heuristic (KC_CHAIN_UNROLL)
-    int resize_mode = 0;  // 0 auto (tiled single pass when a tile fits in LDS), 3 two passes through HBM only (KC_RESIZE_MODE)
+    int resize_mode = 0;  // 0 auto (tiled single pass when a tile fits in LDS), 2 no resize_down_kernel (A/B), 3 two passes through HBM only (KC_RESIZE_MODE)
     int resize_tile_w = 0;  // > 0: force this tile width (KC_RESIZE_TILE_W, tuning only)
     int resize_tile_h = 0;  // > 0: force this tile height for 256-wide tiles (KC_RESIZE_TILE_H, tuning only)
     std::multimap<size_t, void *> free_blocks;

@@ -710,6 +710,162 @@ __global__ __launch_bounds__(256) void resize_wide_kernel(const ResizePlanes P, 
     }
 }
 
+// Down-sampling (more than 8 taps on BOTH axes), second form.  resize_wide_kernel's vertical pass gathers every output
+// row's whole window from global memory (25 16-byte loads per row and column quad for Lanczos3 4:1) with per-lane tap
+// look-ups; here the unit of work is wave-uniform instead:
+//   vertical pass   a WAVE owns R adjacent tile rows and 64 column quads.  It walks the union of the R windows once,
+//                   four source rows per trip (one 16-byte load per lane and row), and feeds each row into every sum
+//                   whose window contains it.  Which sums those are depends only on the rows, not on the lane, so the
+//                   tests are scalar branches on scalar-loaded window bounds and the weights arrive as scalar loads from
+//                   the tap table: (taps + (R - 1) ratio) / R loads per output row instead of taps, no tap staging, no
+//                   per-lane control.  Each sum still receives its taps in ascending order: same roundings.
+//   horizontal pass a lane owns one output column for four tile rows at a time: one weight read and one swizzled
+//                   index per tap serve four sums.
+// Rows whose windows are far apart (the wrapped rows of a row band) fall back to one row per walk.
+// What bounds it (profiles/r02_down_kernel.md): the windows of neighbouring row groups overlap, the overlap is re-read
+// by another wave several trips later and by then has left L2 -- 88 % of this pass's reads miss it -- so the pass runs at
+// the fabric's rate on (taps + (R - 1) ratio) / (R ratio) times the plane.
+template <int R>
+static __device__ __forceinline__ void resize_down_rows(const f4 *__restrict__ src4, uint32_t sp4, float *tmp,
+                                                        uint32_t row_floats, uint32_t nq, uint32_t ty0, uint32_t th,
+                                                        uint32_t y0, const TapsDev &V, uint32_t lane)
+{
+    uint32_t left[R], cnt[R];
+    const float *w[R];
+    uint32_t smin = 0xFFFFFFFFu, smax = 0u;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const bool on = ty0 + k < th;
+        const uint32_t y = y0 + (on ? ty0 + k : ty0);
+        left[k] = V.left[y];
+        cnt[k] = on ? V.count[y] : 0u;
+        w[k] = V.w + (size_t)y * V.stride;
+        if (on) {
+            smin = min(smin, left[k]);
+            smax = max(smax, left[k] + cnt[k]);
+        }
+    }
+    for (uint32_t qb = 0; qb < nq; qb += 64u) {
+        const uint32_t q = min(qb + lane, nq - 1u);
+        const f4 *col = src4 + q;
+        f4 acc[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) acc[k] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+        for (uint32_t s0 = smin; s0 < smax; s0 += 4u) {
+            f4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = col[(size_t)min(s0 + u, smax - 1u) * sp4];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const uint32_t j0 = s0 - left[k];  // wraps for rows above the window
+                if (s0 >= left[k] && j0 + 3u < cnt[k]) {
+                    const float w0 = w[k][j0], w1 = w[k][j0 + 1u], w2 = w[k][j0 + 2u], w3 = w[k][j0 + 3u];
+                    acc[k] += p[0] * w0;
+                    acc[k] += p[1] * w1;
+                    acc[k] += p[2] * w2;
+                    acc[k] += p[3] * w3;
+                } else if (s0 + 3u >= left[k] && s0 < left[k] + cnt[k]) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t j = j0 + (uint32_t)u;
+                        if (j < cnt[k]) acc[k] += p[u] * w[k][j];  // j wraps to a huge value above the window
+                    }
+                }
+            }
+        }
+        if (qb + lane < nq) {
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (ty0 + k < th) {
+                    float *o = tmp + (ty0 + k) * row_floats + 4u * q + (q >> 3);  // a quad never straddles a multiple of 32
+                    o[0] = acc[k].x;
+                    o[1] = acc[k].y;
+                    o[2] = acc[k].z;
+                    o[3] = acc[k].w;
+                }
+        }
+    }
+}
+
+template <int R>  // tile rows per wave: the tile is 4 R rows high
+__global__ __launch_bounds__(256) void resize_down_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
+                                                          TapsDev H, uint32_t tile_w, uint32_t ncp)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr uint32_t tile_h = 4u * R;
+    const float *__restrict__ src = P.src[blockIdx.z];
+    float *__restrict__ dst = P.dst[blockIdx.z];
+    const uint32_t spitch = P.spitch[blockIdx.z], dpitch = P.dpitch[blockIdx.z];
+    const uint32_t x0 = blockIdx.x * tile_w, x1 = min(x0 + tile_w, dw), tw = x1 - x0;
+    const uint32_t y0 = blockIdx.y * tile_h, th = min(y0 + tile_h, dh) - y0;
+    const uint32_t c0 = H.left[x0] & ~3u;
+    const uint32_t nq = (H.left[x1 - 1] + H.count[x1 - 1] - c0 + 3u) / 4u;  // <= ncp / 4 (host-checked)
+    const uint32_t row_floats = ncp + (ncp >> 5) + 1u;
+    const uint32_t hsp = H.stride | 1u;  // odd pitch: the lanes' weight rows start on different banks
+    float *tmp = lds;
+    uint32_t *hl = reinterpret_cast<uint32_t *>(lds + tile_h * row_floats);
+    uint32_t *hn = hl + tile_w;
+    float *hw = reinterpret_cast<float *>(hn + tile_w);  // tile_w x hsp
+    for (uint32_t i = threadIdx.x; i < tw; i += 256u) {
+        hl[i] = H.left[x0 + i] - c0;
+        hn[i] = H.count[x0 + i];
+    }
+    for (uint32_t i = threadIdx.x; i < tw * H.stride; i += 256u) {
+        const uint32_t x = i / H.stride, j = i - x * H.stride;
+        hw[x * hsp + j] = H.w[(size_t)x0 * H.stride + i];
+    }
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    const f4 *src4 = reinterpret_cast<const f4 *>(src + c0);
+    {
+        const uint32_t ty0 = wave * R;
+        // the union of the wave's windows, against the windows themselves
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u, sum = 0u;
+        for (uint32_t k = 0; k < R && ty0 + k < th; ++k) {
+            const uint32_t l = V.left[y0 + ty0 + k], n = V.count[y0 + ty0 + k];
+            lo = min(lo, l);
+            hi = max(hi, l + n);
+            sum += n;
+        }
+        if (hi - lo <= sum) {
+            resize_down_rows<R>(src4, spitch / 4u, tmp, row_floats, nq, ty0, th, y0, V, lane);
+        } else {
+            for (uint32_t k = 0; k < R && ty0 + k < th; ++k)
+                resize_down_rows<1>(src4, spitch / 4u, tmp, row_floats, nq, ty0 + k, th, y0, V, lane);
+        }
+    }
+    __syncthreads();
+    if (lane < tw) {
+        const uint32_t n = hn[lane], h0 = hl[lane];
+        const float *w = hw + lane * hsp;
+        for (uint32_t tb = wave * 4u; tb < th; tb += 16u) {
+            const float *row = tmp + tb * row_floats;
+            float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (uint32_t j0 = 0; j0 < n; j0 += 4u) {
+                float p[4][4], wt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t jj = min(j0 + u, n - 1u);
+                    const uint32_t idx = h0 + jj;
+                    const uint32_t sidx = idx + (idx >> 5);
+                    wt[u] = w[jj];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[u][r] = row[r * row_floats + sidx];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool live = j0 + u < n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] += live ? p[u][r] * wt[u] : -0.0f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (tb + r < th) dst[(size_t)(y0 + tb + r) * dpitch + x0 + lane] = clamp01_nan_passthrough(t[r]);
+        }
+    }
+}
+
 // Fused resample + Mix chain: phase 2's four results are input slot K-1 of the chain program, the
 // other K-1 inputs are resident planes read with one 16-byte load each, and only the chain's
 // result is stored.  The resampled plane itself never exists in HBM: per output pixel the launch
@@ -824,6 +980,21 @@ hipError_t launch_resize_lds(const ResizePlanes &p, int batch, uint32_t dw, uint
         launch_resize_lds_t<2>(grid, lds, s, h.stride, p, dw, dh, v, h, tile_w, tile_h, ncp);
     else
         launch_resize_lds_t<1>(grid, lds, s, h.stride, p, dw, dh, v, h, tile_w, tile_h, ncp);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_down(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,
+                              uint32_t tile_h, uint32_t ncp, hipStream_t s)
+{
+    if (dw == 0 || dh == 0) return hipSuccess;
+    if (batch < 1 || batch > 4) return hipErrorInvalidValue;
+    if (tile_w == 0 || tile_w > 64 || (tile_h != 16 && tile_h != 32) || ncp % 4 != 0) return hipErrorInvalidValue;
+    const size_t lds = resize_down_lds_bytes(tile_h, ncp, tile_w, h.stride);
+    dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h, batch);
+    if (tile_h == 16)
+        resize_down_kernel<4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp);
+    else
+        resize_down_kernel<8><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp);
     return hipGetLastError();
 }
 

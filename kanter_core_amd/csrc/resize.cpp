@@ -259,6 +259,7 @@ static int resize_plane(kc_plane *src, kc_size size, int filter, kc_plane **out)
 struct TileChoice {
     uint32_t tile_w = 0, tile_h = 0, ncp = 0;
     bool ok = false;
+    bool down = false;  // resize_down_kernel (both axes wider than the register-tap forms)
 };
 
 static bool tile_fits(const TapsEntry &tv, const TapsEntry &th, kc_size size, uint32_t tw, uint32_t tht, size_t budget, TileChoice &t)
@@ -277,6 +278,21 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
 {
     Context &c = ctx();
     TileChoice t;
+    // Both axes down-sampled: the wave-uniform form.  Its vertical pass deals 64 column quads to a wave, so the widest
+    // tile whose source window is at most 64 quads wastes no lanes; a wave walks 4 (tile of 16) or 8 (tile of 32) rows.
+    if (th.dev.stride > KC_RESIZE_REG_TAPS && tv.dev.stride > KC_RESIZE_REG_TAPS && c.resize_mode != 2) {
+        const uint32_t rows = c.resize_tile_h == 32 ? 32u : 16u;  // KC_RESIZE_TILE_H=32: tuning
+        for (uint32_t tw = 64; tw >= 4; tw -= 4) {
+            const uint32_t groups = tile_groups(th.host, size.width, tw);
+            if (groups > 64 && tw > 4) continue;
+            if (resize_down_lds_bytes(rows, 4u * groups, tw, th.dev.stride) > 64 * 1024) continue;
+            t.tile_w = tw;
+            t.tile_h = rows;
+            t.ncp = 4u * groups;
+            t.ok = t.down = true;
+            return t;
+        }
+    }
     if (c.resize_tile_w > 0 && c.resize_tile_h > 0 &&  // tuning override (KC_RESIZE_TILE_W / _H)
         tile_fits(tv, th, size, (uint32_t)c.resize_tile_w, (uint32_t)c.resize_tile_h, 64 * 1024, t))
         return t;
@@ -316,8 +332,9 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 rp.spitch[i] = (uint32_t)(srcs[i]->pitch / 4);
                 rp.dpitch[i] = (uint32_t)(dsts[i]->pitch / 4);
             }
-            hipError_t e = launch_resize_lds(rp, n, size.width, size.height, tv->dev, th->dev, th->host.min_count, t.tile_w,
-                                             t.tile_h, t.ncp, c.stream);
+            hipError_t e = t.down ? launch_resize_down(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, c.stream)
+                                  : launch_resize_lds(rp, n, size.width, size.height, tv->dev, th->dev, th->host.min_count, t.tile_w,
+                                                      t.tile_h, t.ncp, c.stream);
             if (e != hipSuccess) return hip_fail(e, "launch_resize_lds");
             c.launches++;
             c.alg_bytes += (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height);
