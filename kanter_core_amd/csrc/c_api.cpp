@@ -109,6 +109,12 @@ try {
     (void)hipStreamSynchronize(c.stream);
     specialize_shutdown();
     pool_trim();
+    for (auto &us : c.upload_ring) {
+        if (us.copied) (void)hipEventDestroy(us.copied);
+        if (us.host) (void)hipHostFree(us.host);
+        us = Context::UploadSlot{};
+    }
+    c.upload_next = 0;
     for (auto &kv : c.taps) (void)hipFree(kv.second.dev_block);
     c.taps.clear();
     for (auto &kv : c.band_taps) (void)hipFree(kv.second.dev_block);

@@ -190,6 +190,17 @@ struct Context {
     // are immutable, so the result is identical).  Both planes are retained while memoised.
     int memo_depth = 0;
     std::map<std::tuple<kc_plane *, uint32_t, uint32_t, int>, kc_plane *> resize_memo;
+    // image_from_u8's pinned staging ring: the caller's pixels are copied into a slot, the slot is DMA'd and the
+    // call returns without waiting for the stream; a slot is reused once the event recorded behind its copy has fired.
+    struct UploadSlot {
+        void *host = nullptr;
+        size_t bytes = 0;
+        hipEvent_t copied = nullptr;
+    };
+    static constexpr int kUploadSlots = 4;
+    static constexpr size_t kUploadSlotMax = (size_t)4 << 20;  // larger images keep the synchronous path
+    UploadSlot upload_ring[kUploadSlots];
+    int upload_next = 0;
 };
 
 // RAII scope for the resize memo (nested Graph nodes share the outermost scope).

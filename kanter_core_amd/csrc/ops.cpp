@@ -1,6 +1,7 @@
 // Node operators: the bodies behind process_node_internal (src/node/node_type.rs:98-138) and the
 // SlotImage conversions they use.  Host logic only decides WHICH planes feed which kernel; every
 // pixel is produced by a kernel in kernels.hip.
+#include <cstdlib>
 #include <cstring>
 
 #include "kc_runtime.hpp"
@@ -81,11 +82,39 @@ int image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_
         }
     }
     if (s == KC_OK) {
-        hipError_t e = hipMemcpyAsync(staging, host, nbytes, hipMemcpyHostToDevice, c.stream);
+        hipError_t e = hipSuccess;
+        // The caller may free `host` as soon as we return.  Small images (the reference's own sizes) go through a pinned
+        // ring slot and the call does not wait for the stream; larger ones are copied from `host` directly and waited for.
+        Context::UploadSlot *slot = nullptr;
+        static const bool ring_on = !std::getenv("KC_UPLOAD_RING") || std::atoi(std::getenv("KC_UPLOAD_RING")) != 0;  // 0: A/B
+        if (ring_on && nbytes <= Context::kUploadSlotMax) {
+            slot = &c.upload_ring[c.upload_next];
+            c.upload_next = (c.upload_next + 1) % Context::kUploadSlots;
+            if (slot->bytes < nbytes) {
+                if (slot->host) {
+                    if (slot->copied) (void)hipEventSynchronize(slot->copied);
+                    (void)hipHostFree(slot->host);
+                    slot->host = nullptr;
+                    slot->bytes = 0;
+                }
+                const size_t want = std::max(nbytes, (size_t)256 << 10);
+                e = hipHostMalloc(&slot->host, want, hipHostMallocDefault);
+                if (e == hipSuccess) slot->bytes = want;
+                else slot->host = nullptr;
+            }
+            if (e == hipSuccess && !slot->copied) e = hipEventCreateWithFlags(&slot->copied, hipEventDisableTiming);
+            else if (e == hipSuccess) e = hipEventSynchronize(slot->copied);  // the slot's previous upload
+            if (e == hipSuccess) {
+                std::memcpy(slot->host, host, nbytes);
+                e = hipMemcpyAsync(staging, slot->host, nbytes, hipMemcpyHostToDevice, c.stream);
+                if (e == hipSuccess) e = hipEventRecord(slot->copied, c.stream);
+            }
+        } else {
+            e = hipMemcpyAsync(staging, host, nbytes, hipMemcpyHostToDevice, c.stream);
+        }
         if (e == hipSuccess)
             e = launch_from_u8((const uint8_t *)staging, channels, w, h, dp, (uint32_t)(p[0]->pitch / 4), c.stream);
-        // the caller may free `host` as soon as we return (pageable memory can be DMA'd in place)
-        if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+        if (e == hipSuccess && !slot) e = hipStreamSynchronize(c.stream);
         if (e != hipSuccess) s = hip_fail(e, "image_from_u8");
         else {
             c.launches++;
