@@ -130,3 +130,25 @@ def test_to_u8_4096_vs_oracle(kc, orc, planes4096):
     a, _ = planes4096
     got = kc.SlotImage.from_planes(a).to_u8()
     assert np.array_equal(got, orc.to_u8(orc.Image(a)))
+
+
+# Down-sampling on both axes at full size (resize_down_kernel: ~1 200 tiles, partial last tiles in both directions,
+# non-integer ratios, widths that are not multiples of 4), with non-finite samples that must stay inside their windows.
+@pytest.mark.parametrize("filt,src,dst", [
+    ("Lanczos3", (4096, 4096), (1024, 1024)),
+    ("Gaussian", (3000, 3000), (700, 700)),
+    ("CatmullRom", (4096, 4096), (1365, 1365)),
+    ("Triangle", (4093, 2050), (511, 259)),
+    ("Lanczos3", (4096, 4096), (3000, 3000)),
+])
+def test_resize_down_full_size_vs_oracle(kc, orc, filt, src, dst):
+    (sw, sh), (dw, dh) = src, dst
+    p = splitmix_plane(SEED_B, 1, sh, sw) * np.float32(1.5) - np.float32(0.25)  # exercises the [0, 1] clamp
+    p[sh // 2, sw // 2 - 2:sw // 2 + 2] = [np.nan, np.inf, -np.inf, -0.0]
+    p[0, 0] = np.inf
+    p[-1, -1] = -np.inf
+    got = kc.resize_image(kc.SlotImage.from_planes([p]), (dw, dh), kc.ResizeFilter.parse(filt)).planes()[0]
+    want = orc.resize_plane(p, dw, dh, filt)
+    assert bit_equal(got, want), "%s %s->%s" % (filt, src, dst)
+    # the non-finite samples reach exactly the outputs whose windows contain them
+    assert np.isnan(got).sum() == np.isnan(want).sum() > 0
