@@ -159,6 +159,9 @@ struct TapsHost {
     std::vector<float> w;
     uint32_t stride = 1;     // max taps of any output index
     uint32_t min_count = 1;  // min taps of any output index
+    // Integer-ratio down-sampling: output indices [reg_a, reg_b) all have reg_ages * reg_ratio taps, windows reg_ratio
+    // apart and bit-identical weights (resize_poly_kernel); reg_ratio == 0: no such range.
+    uint32_t reg_a = 0, reg_b = 0, reg_ages = 0, reg_ratio = 0;
 };
 
 struct TapsEntry {
@@ -177,7 +180,7 @@ struct Context {
     bool fusion = true;
     int max_blocks = 4096;
     int chain_unroll = 0;  // float4 per thread per decode in the chain kernel; 0 = heuristic (KC_CHAIN_UNROLL)
-    int resize_mode = 0;  // 0 auto (tiled single pass when a tile fits in LDS), 2 no resize_down_kernel (A/B), 3 two passes through HBM only (KC_RESIZE_MODE)
+    int resize_mode = 0;  // 0 auto (tiled single pass when a tile fits in LDS), 1 no resize_poly_kernel, 2 no resize_down_kernel either (A/B), 3 two passes through HBM only (KC_RESIZE_MODE)
     int resize_tile_w = 0;  // > 0: force this tile width (KC_RESIZE_TILE_W, tuning only)
     int resize_tile_h = 0;  // > 0: force this tile height for 256-wide tiles (KC_RESIZE_TILE_H, tuning only)
     std::multimap<size_t, void *> free_blocks;

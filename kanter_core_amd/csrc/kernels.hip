@@ -9,6 +9,7 @@
 // Reference paths are relative to the reference checkout.
 #include "kc_internal.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace kc {
@@ -787,36 +788,77 @@ static __device__ __forceinline__ void resize_down_rows(const f4 *__restrict__ s
     }
 }
 
-template <int R>  // tile rows per wave: the tile is 4 R rows high
-__global__ __launch_bounds__(256) void resize_down_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
-                                                          TapsDev H, uint32_t tile_w, uint32_t ncp)
+// The strip's horizontal taps, staged once per workgroup (every wave of it works on the same output columns).
+struct DownStrip {
+    uint32_t x0, tw, c0, nq, row_floats, hsp;
+    float *tmp;
+    uint32_t *hl, *hn;
+    float *hw;
+};
+
+static __device__ __forceinline__ DownStrip resize_down_stage(float *lds, const TapsDev &H, uint32_t dw, uint32_t tile_w,
+                                                              uint32_t tmp_rows, uint32_t ncp)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr uint32_t tile_h = 4u * R;
-    const float *__restrict__ src = P.src[blockIdx.z];
-    float *__restrict__ dst = P.dst[blockIdx.z];
-    const uint32_t spitch = P.spitch[blockIdx.z], dpitch = P.dpitch[blockIdx.z];
-    const uint32_t x0 = blockIdx.x * tile_w, x1 = min(x0 + tile_w, dw), tw = x1 - x0;
-    const uint32_t y0 = blockIdx.y * tile_h, th = min(y0 + tile_h, dh) - y0;
-    const uint32_t c0 = H.left[x0] & ~3u;
-    const uint32_t nq = (H.left[x1 - 1] + H.count[x1 - 1] - c0 + 3u) / 4u;  // <= ncp / 4 (host-checked)
-    const uint32_t row_floats = ncp + (ncp >> 5) + 1u;
-    const uint32_t hsp = H.stride | 1u;  // odd pitch: the lanes' weight rows start on different banks
-    float *tmp = lds;
-    uint32_t *hl = reinterpret_cast<uint32_t *>(lds + tile_h * row_floats);
-    uint32_t *hn = hl + tile_w;
-    float *hw = reinterpret_cast<float *>(hn + tile_w);  // tile_w x hsp
-    for (uint32_t i = threadIdx.x; i < tw; i += 256u) {
-        hl[i] = H.left[x0 + i] - c0;
-        hn[i] = H.count[x0 + i];
+    DownStrip S;
+    S.x0 = blockIdx.x * tile_w;
+    const uint32_t x1 = min(S.x0 + tile_w, dw);
+    S.tw = x1 - S.x0;
+    S.c0 = H.left[S.x0] & ~3u;
+    S.nq = (H.left[x1 - 1] + H.count[x1 - 1] - S.c0 + 3u) / 4u;  // <= ncp / 4 (host-checked)
+    S.row_floats = ncp + (ncp >> 5) + 1u;
+    S.hsp = H.stride | 1u;  // odd pitch: the lanes' weight rows start on different banks
+    S.tmp = lds;
+    S.hl = reinterpret_cast<uint32_t *>(lds + tmp_rows * S.row_floats);
+    S.hn = S.hl + tile_w;
+    S.hw = reinterpret_cast<float *>(S.hn + tile_w);  // tile_w x hsp
+    for (uint32_t i = threadIdx.x; i < S.tw; i += 256u) {
+        S.hl[i] = H.left[S.x0 + i] - S.c0;
+        S.hn[i] = H.count[S.x0 + i];
     }
-    for (uint32_t i = threadIdx.x; i < tw * H.stride; i += 256u) {
+    for (uint32_t i = threadIdx.x; i < S.tw * H.stride; i += 256u) {
         const uint32_t x = i / H.stride, j = i - x * H.stride;
-        hw[x * hsp + j] = H.w[(size_t)x0 * H.stride + i];
+        S.hw[x * S.hsp + j] = H.w[(size_t)S.x0 * H.stride + i];
     }
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t lane = threadIdx.x & 63u;
-    const f4 *src4 = reinterpret_cast<const f4 *>(src + c0);
+    return S;
+}
+
+// Horizontal pass of four intermediate rows (row, row + row_floats, ...) for this lane's output column.
+static __device__ __forceinline__ void resize_down_hrows(const DownStrip &S, const float *row, uint32_t lane, float *dst_row,
+                                                         uint32_t dpitch, uint32_t nrows)
+{
+    const uint32_t n = S.hn[lane], h0 = S.hl[lane];
+    const float *w = S.hw + lane * S.hsp;
+    float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    for (uint32_t j0 = 0; j0 < n; j0 += 4u) {
+        float p[4][4], wt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t jj = min(j0 + u, n - 1u);
+            const uint32_t idx = h0 + jj;
+            const uint32_t sidx = idx + (idx >> 5);
+            wt[u] = w[jj];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[u][r] = row[r * S.row_floats + sidx];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = j0 + u < n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] += live ? p[u][r] * wt[u] : -0.0f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if ((uint32_t)r < nrows) dst_row[(size_t)r * dpitch + S.x0 + lane] = clamp01_nan_passthrough(t[r]);
+}
+
+// One tile of 4 R rows at y0 (th of them exist): the general form, any windows.  Called by all four waves.
+template <int R>
+static __device__ __forceinline__ void resize_down_tile(const DownStrip &S, const float *__restrict__ src, uint32_t spitch,
+                                                        float *__restrict__ dst, uint32_t dpitch, uint32_t y0, uint32_t th,
+                                                        const TapsDev &V, uint32_t wave, uint32_t lane)
+{
+    const f4 *src4 = reinterpret_cast<const f4 *>(src + S.c0);
     {
         const uint32_t ty0 = wave * R;
         // the union of the wave's windows, against the windows themselves
@@ -828,41 +870,129 @@ __global__ __launch_bounds__(256) void resize_down_kernel(const ResizePlanes P, 
             sum += n;
         }
         if (hi - lo <= sum) {
-            resize_down_rows<R>(src4, spitch / 4u, tmp, row_floats, nq, ty0, th, y0, V, lane);
+            resize_down_rows<R>(src4, spitch / 4u, S.tmp, S.row_floats, S.nq, ty0, th, y0, V, lane);
         } else {
             for (uint32_t k = 0; k < R && ty0 + k < th; ++k)
-                resize_down_rows<1>(src4, spitch / 4u, tmp, row_floats, nq, ty0 + k, th, y0, V, lane);
+                resize_down_rows<1>(src4, spitch / 4u, S.tmp, S.row_floats, S.nq, ty0 + k, th, y0, V, lane);
         }
     }
     __syncthreads();
-    if (lane < tw) {
-        const uint32_t n = hn[lane], h0 = hl[lane];
-        const float *w = hw + lane * hsp;
-        for (uint32_t tb = wave * 4u; tb < th; tb += 16u) {
-            const float *row = tmp + tb * row_floats;
-            float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-            for (uint32_t j0 = 0; j0 < n; j0 += 4u) {
-                float p[4][4], wt[4];
+    if (lane < S.tw)
+        for (uint32_t tb = wave * 4u; tb < th; tb += 16u)
+            resize_down_hrows(S, S.tmp + tb * S.row_floats, lane, dst + (size_t)(y0 + tb) * dpitch, dpitch, th - tb);
+}
+
+template <int R>  // tile rows per wave: the tile is 4 R rows high
+__global__ __launch_bounds__(256) void resize_down_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
+                                                          TapsDev H, uint32_t tile_w, uint32_t ncp)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr uint32_t tile_h = 4u * R;
+    const DownStrip S = resize_down_stage(lds, H, dw, tile_w, tile_h, ncp);
+    const uint32_t y0 = blockIdx.y * tile_h, th = min(y0 + tile_h, dh) - y0;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    resize_down_tile<R>(S, P.src[blockIdx.z], P.spitch[blockIdx.z], P.dst[blockIdx.z], P.dpitch[blockIdx.z], y0, th, V, wave,
+                        threadIdx.x & 63u);
+}
+
+// Integer-ratio down-sampling (4096 -> 1024, -> 512, -> 2048 ...): away from the image border every output row has the
+// same n = A * RT weights and its window starts RT source rows below its neighbour's (the host checks this bit for bit,
+// TapsHost::reg_*).  A wave then STREAMS a band of 16 such rows: RT source rows per trip; the sum of "age" a (the row
+// whose window began a trips ago) receives its taps a RT .. a RT + RT - 1 from them; after the trip the oldest sum is
+// complete, goes to a four-row LDS ring and the sums move up one age.  No window test, no weight fetch (the A * RT weights
+// sit in scalar registers), every source row of the band is loaded once, and after each four finished rows the wave runs the
+// horizontal pass on its ring by itself: no barrier after the tap staging.  Same taps in the same order: same roundings.
+// Rows near the border (and what does not fill a band) are tiles of the general form, run by the launch's last workgroups.
+struct PolyBands {
+    uint32_t ya;        // first regular row handled as a band
+    uint32_t n_bands;   // bands of 16 rows from ya
+    uint32_t nyb;       // workgroups (of 4 bands) along y; the general tiles follow
+    uint32_t ty0[4], th[4];  // general tiles: first row, rows (<= 16)
+};
+
+template <int A, int RT>
+__global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
+                                                          TapsDev H, uint32_t tile_w, uint32_t ncp, PolyBands B)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const DownStrip S = resize_down_stage(lds, H, dw, tile_w, 16u, ncp);
+    const float *__restrict__ src = P.src[blockIdx.z];
+    float *__restrict__ dst = P.dst[blockIdx.z];
+    const uint32_t spitch = P.spitch[blockIdx.z], dpitch = P.dpitch[blockIdx.z];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.y >= B.nyb) {
+        const uint32_t t = blockIdx.y - B.nyb;
+        resize_down_tile<4>(S, src, spitch, dst, dpitch, B.ty0[t], B.th[t], V, wave, lane);
+        return;
+    }
+    __syncthreads();  // the strip's horizontal taps
+    const uint32_t bi = blockIdx.y * 4u + wave;
+    if (bi >= B.n_bands) return;
+    constexpr uint32_t ROWS = 16u;
+    const uint32_t yf = B.ya + ROWS * bi;
+    float W[A][RT];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t jj = min(j0 + u, n - 1u);
-                    const uint32_t idx = h0 + jj;
-                    const uint32_t sidx = idx + (idx >> 5);
-                    wt[u] = w[jj];
+    for (int a = 0; a < A; ++a)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p[u][r] = row[r * row_floats + sidx];
-                }
+        for (int u = 0; u < RT; ++u) W[a][u] = V.w[(size_t)B.ya * V.stride + a * RT + u];
+    const uint32_t sp4 = spitch / 4u;
+    const bool q_ok = lane < S.nq;
+    const uint32_t q = min(lane, S.nq - 1u);
+    const f4 *col = reinterpret_cast<const f4 *>(src + S.c0) + q + (size_t)V.left[yf] * sp4;
+    float *ring = S.tmp + wave * 4u * S.row_floats;
+    float *ringq = ring + 4u * q + (q >> 3);  // swizzled: a quad never straddles a multiple of 32
+    f4 acc[A];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool live = j0 + u < n;
+    for (int a = 0; a < A; ++a) acc[a] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    f4 pn[RT];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] += live ? p[u][r] * wt[u] : -0.0f;
-                }
-            }
+    for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)u * sp4];
+    constexpr uint32_t TRIPS = ROWS + A - 1;
+    for (uint32_t c = 0; c < TRIPS; ++c) {
+        f4 p[RT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (tb + r < th) dst[(size_t)(y0 + tb + r) * dpitch + x0 + lane] = clamp01_nan_passthrough(t[r]);
+        for (int u = 0; u < RT; ++u) p[u] = pn[u];
+        if (c + 1u < TRIPS) {
+#pragma unroll
+            for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)((c + 1u) * RT + u) * sp4];
         }
+        // age a holds row c - a of the band
+        if (c >= (uint32_t)(A - 1) && c < ROWS) {
+#pragma unroll
+            for (int u = 0; u < RT; ++u)
+#pragma unroll
+                for (int a = 0; a < A; ++a) acc[a] += p[u] * W[a][u];
+        } else {
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+                if (c >= (uint32_t)a && c - (uint32_t)a < ROWS) {
+#pragma unroll
+                    for (int u = 0; u < RT; ++u) acc[a] += p[u] * W[a][u];
+                }
+        }
+        if (c >= (uint32_t)(A - 1)) {
+            const uint32_t k = c - (uint32_t)(A - 1);  // this row of the band is complete
+            if (q_ok) {
+                float *o = ringq + (k & 3u) * S.row_floats;
+                o[0] = acc[A - 1].x;
+                o[1] = acc[A - 1].y;
+                o[2] = acc[A - 1].z;
+                o[3] = acc[A - 1].w;
+            }
+            if ((k & 3u) == 3u) {
+                // the ring is this wave's own: its lanes' writes only have to be ordered before its lanes' reads
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < S.tw) resize_down_hrows(S, ring, lane, dst + (size_t)(yf + k - 3u) * dpitch, dpitch, 4u);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#pragma unroll
+        for (int a = A - 1; a > 0; --a) acc[a] = acc[a - 1];
+        acc[0] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
     }
 }
 
@@ -995,6 +1125,47 @@ hipError_t launch_resize_down(const ResizePlanes &p, int batch, uint32_t dw, uin
         resize_down_kernel<4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp);
     else
         resize_down_kernel<8><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp);
+    return hipGetLastError();
+}
+
+template <int A>
+static void launch_resize_poly_a(dim3 grid, size_t lds, hipStream_t s, uint32_t rt, const ResizePlanes &p, uint32_t dw, uint32_t dh,
+                                 TapsDev v, TapsDev h, uint32_t tile_w, uint32_t ncp, const PolyBands &b)
+{
+    if (rt == 2) resize_poly_kernel<A, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
+    else if (rt == 4) resize_poly_kernel<A, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
+    else resize_poly_kernel<A, 8><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
+}
+
+// Rows [reg_a, reg_b) of the vertical table are regular: `ages` x `ratio` taps each, windows `ratio` apart, equal weights.
+hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,
+                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, hipStream_t s)
+{
+    if (dw == 0 || dh == 0) return hipSuccess;
+    if (batch < 1 || batch > 4) return hipErrorInvalidValue;
+    if (tile_w == 0 || tile_w > 64 || ncp % 4 != 0 || reg_a > reg_b || reg_b > dh) return hipErrorInvalidValue;
+    if ((ages != 2 && ages != 4 && ages != 6) || (ratio != 2 && ratio != 4 && ratio != 8)) return hipErrorInvalidValue;
+    PolyBands b{};
+    b.ya = reg_a;
+    b.n_bands = (reg_b - reg_a) / 16u;
+    b.nyb = (b.n_bands + 3u) / 4u;
+    // what is left: rows above the first band and below the last one, as general tiles of at most 16 rows
+    uint32_t nt = 0;
+    auto add_tiles = [&](uint32_t y0, uint32_t y1) {
+        for (uint32_t y = y0; y < y1; y += 16u) {
+            if (nt == 4) return false;
+            b.ty0[nt] = y;
+            b.th[nt] = std::min(16u, y1 - y);
+            ++nt;
+        }
+        return true;
+    };
+    if (!add_tiles(0, reg_a) || !add_tiles(reg_a + 16u * b.n_bands, dh)) return hipErrorInvalidValue;
+    const size_t lds = resize_down_lds_bytes(16, ncp, tile_w, h.stride);
+    dim3 grid((dw + tile_w - 1) / tile_w, b.nyb + nt, batch);
+    if (ages == 2) launch_resize_poly_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
+    else if (ages == 4) launch_resize_poly_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
+    else launch_resize_poly_a<6>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
     return hipGetLastError();
 }
 

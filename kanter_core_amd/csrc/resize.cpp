@@ -96,6 +96,35 @@ int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
         }
         for (uint32_t j = 0; j < t.count[o]; ++j) w[j] /= sum;
     }
+    // The longest run of output indices whose windows are equally long, a whole number `step` of source samples apart, and
+    // weighted bit-identically -- what integer-ratio down-sampling gives away from the border (resize_poly_kernel).
+    t.reg_a = t.reg_b = t.reg_ages = t.reg_ratio = 0;
+    if (out_n >= 2 && t.stride > KC_RESIZE_REG_TAPS) {
+        uint32_t best_a = 0, best_b = 0, a0 = 0;
+        auto same = [&](uint32_t x, uint32_t y) {
+            return t.count[x] == t.count[y] && std::memcmp(&t.w[(size_t)x * t.stride], &t.w[(size_t)y * t.stride], t.count[x] * sizeof(float)) == 0;
+        };
+        for (uint32_t o = 1; o <= out_n; ++o) {
+            const bool cont = o < out_n && same(o, a0) && (o == a0 + 1 || t.left[o] - t.left[o - 1] == t.left[a0 + 1] - t.left[a0]) &&
+                              t.left[o] > t.left[o - 1];
+            if (!cont) {
+                if (o - a0 > best_b - best_a) {
+                    best_a = a0;
+                    best_b = o;
+                }
+                a0 = o;
+            }
+        }
+        if (best_b - best_a >= 2) {
+            const uint32_t step = t.left[best_a + 1] - t.left[best_a], n = t.count[best_a];
+            if (step >= 2 && n % step == 0) {
+                t.reg_a = best_a;
+                t.reg_b = best_b;
+                t.reg_ratio = step;
+                t.reg_ages = n / step;
+            }
+        }
+    }
     return KC_OK;
 }
 
@@ -260,6 +289,7 @@ struct TileChoice {
     uint32_t tile_w = 0, tile_h = 0, ncp = 0;
     bool ok = false;
     bool down = false;  // resize_down_kernel (both axes wider than the register-tap forms)
+    bool poly = false;  // ... and its vertical table is regular: resize_poly_kernel
 };
 
 static bool tile_fits(const TapsEntry &tv, const TapsEntry &th, kc_size size, uint32_t tw, uint32_t tht, size_t budget, TileChoice &t)
@@ -290,6 +320,10 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
             t.tile_h = rows;
             t.ncp = 4u * groups;
             t.ok = t.down = true;
+            const TapsHost &hv = tv.host;
+            t.poly = rows == 16 && c.resize_mode != 1 && (hv.reg_ages == 2 || hv.reg_ages == 4 || hv.reg_ages == 6) &&
+                     (hv.reg_ratio == 2 || hv.reg_ratio == 4 || hv.reg_ratio == 8) && hv.reg_b - hv.reg_a >= 16 && hv.reg_a <= 16 &&
+                     size.height - (hv.reg_a + (hv.reg_b - hv.reg_a) / 16 * 16) <= 48;
             return t;
         }
     }
@@ -332,7 +366,9 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 rp.spitch[i] = (uint32_t)(srcs[i]->pitch / 4);
                 rp.dpitch[i] = (uint32_t)(dsts[i]->pitch / 4);
             }
-            hipError_t e = t.down ? launch_resize_down(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, c.stream)
+            hipError_t e = t.poly ? launch_resize_poly(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.ncp, tv->host.reg_a,
+                                                       tv->host.reg_b, tv->host.reg_ages, tv->host.reg_ratio, c.stream)
+                           : t.down ? launch_resize_down(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, c.stream)
                                   : launch_resize_lds(rp, n, size.width, size.height, tv->dev, th->dev, th->host.min_count, t.tile_w,
                                                       t.tile_h, t.ncp, c.stream);
             if (e != hipSuccess) return hip_fail(e, "launch_resize_lds");
