@@ -829,6 +829,26 @@ static __device__ __forceinline__ void resize_down_hrows(const DownStrip &S, con
     const uint32_t n = S.hn[lane], h0 = S.hl[lane];
     const float *w = S.hw + lane * S.hsp;
     float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    // Every column of the strip has the same number of taps, a multiple of 4 (the interior of an integer-ratio resample):
+    // no tap needs clamping or masking.
+    const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+    if ((nu & 3u) == 0u && __builtin_amdgcn_ballot_w64(n != nu) == 0ull) {
+        for (uint32_t j0 = 0; j0 < nu; j0 += 4u) {
+            float p[4][4], wt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t idx = h0 + j0 + u;
+                const uint32_t sidx = idx + (idx >> 5);
+                wt[u] = w[j0 + u];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[u][r] = row[r * S.row_floats + sidx];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] += p[u][r] * wt[u];
+        }
+    } else
     for (uint32_t j0 = 0; j0 < n; j0 += 4u) {
         float p[4][4], wt[4];
 #pragma unroll
@@ -897,15 +917,16 @@ __global__ __launch_bounds__(256) void resize_down_kernel(const ResizePlanes P, 
 
 // Integer-ratio down-sampling (4096 -> 1024, -> 512, -> 2048 ...): away from the image border every output row has the
 // same n = A * RT weights and its window starts RT source rows below its neighbour's (the host checks this bit for bit,
-// TapsHost::reg_*).  A wave then STREAMS a band of 16 such rows: RT source rows per trip; the sum of "age" a (the row
+// TapsHost::reg_*).  A wave then STREAMS a band of 12 such rows: RT source rows per trip; the sum of "age" a (the row
 // whose window began a trips ago) receives its taps a RT .. a RT + RT - 1 from them; after the trip the oldest sum is
 // complete, goes to a four-row LDS ring and the sums move up one age.  No window test, no weight fetch (the A * RT weights
 // sit in scalar registers), every source row of the band is loaded once, and after each four finished rows the wave runs the
 // horizontal pass on its ring by itself: no barrier after the tap staging.  Same taps in the same order: same roundings.
 // Rows near the border (and what does not fill a band) are tiles of the general form, run by the launch's last workgroups.
 struct PolyBands {
-    uint32_t ya;        // first regular row handled as a band
-    uint32_t n_bands;   // bands of 16 rows from ya
+    uint32_t ya, yb;    // regular rows handled as bands: [ya, yb), yb - ya a multiple of 4
+    uint32_t rows;      // rows per band (a multiple of 4; the last band may be shorter)
+    uint32_t n_bands;
     uint32_t nyb;       // workgroups (of 4 bands) along y; the general tiles follow
     uint32_t ty0[4], th[4];  // general tiles: first row, rows (<= 16)
 };
@@ -929,13 +950,13 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
     __syncthreads();  // the strip's horizontal taps
     const uint32_t bi = blockIdx.y * 4u + wave;
     if (bi >= B.n_bands) return;
-    constexpr uint32_t ROWS = 16u;
-    const uint32_t yf = B.ya + ROWS * bi;
+    const uint32_t yf = B.ya + B.rows * bi;
+    const uint32_t ROWS = min(B.rows, B.yb - yf);
     float W[A][RT];
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
-        for (int u = 0; u < RT; ++u) W[a][u] = V.w[(size_t)B.ya * V.stride + a * RT + u];
+        for (int u = 0; u < RT; ++u) W[a][u] = V.w[(size_t)B.ya * V.stride + a * RT + u];  // scalar registers (vector ones measured slower)
     const uint32_t sp4 = spitch / 4u;
     const bool q_ok = lane < S.nq;
     const uint32_t q = min(lane, S.nq - 1u);
@@ -948,7 +969,7 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
     f4 pn[RT];
 #pragma unroll
     for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)u * sp4];
-    constexpr uint32_t TRIPS = ROWS + A - 1;
+    const uint32_t TRIPS = ROWS + A - 1;
     for (uint32_t c = 0; c < TRIPS; ++c) {
         f4 p[RT];
 #pragma unroll
@@ -1147,7 +1168,13 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     if ((ages != 2 && ages != 4 && ages != 6) || (ratio != 2 && ratio != 4 && ratio != 8)) return hipErrorInvalidValue;
     PolyBands b{};
     b.ya = reg_a;
-    b.n_bands = (reg_b - reg_a) / 16u;
+    b.yb = reg_a + (reg_b - reg_a) / 4u * 4u;
+    // Band height: 12 rows.  Measured on one box (profiles/r02_down_kernel.md): 8 / 12 / 16 rows give 28.7 / 24.5 / 27.7 us on
+    // Lanczos3 4:1 -- shorter bands re-read more of their neighbours' windows, taller ones leave too few waves to overlap
+    // one wave's arithmetic with another's loads; bands sized for one wave per SIMD (20+ rows) were slower still.
+    static const uint32_t rows = std::getenv("KC_POLY_ROWS") ? std::max(4u, (uint32_t)std::atoi(std::getenv("KC_POLY_ROWS")) / 4u * 4u) : 12u;
+    b.rows = rows;
+    b.n_bands = (b.yb - b.ya + b.rows - 1) / b.rows;
     b.nyb = (b.n_bands + 3u) / 4u;
     // what is left: rows above the first band and below the last one, as general tiles of at most 16 rows
     uint32_t nt = 0;
@@ -1160,7 +1187,7 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
         }
         return true;
     };
-    if (!add_tiles(0, reg_a) || !add_tiles(reg_a + 16u * b.n_bands, dh)) return hipErrorInvalidValue;
+    if (!add_tiles(0, b.ya) || !add_tiles(b.yb, dh)) return hipErrorInvalidValue;
     const size_t lds = resize_down_lds_bytes(16, ncp, tile_w, h.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, b.nyb + nt, batch);
     if (ages == 2) launch_resize_poly_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);

@@ -323,7 +323,7 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
             const TapsHost &hv = tv.host;
             t.poly = rows == 16 && c.resize_mode != 1 && (hv.reg_ages == 2 || hv.reg_ages == 4 || hv.reg_ages == 6) &&
                      (hv.reg_ratio == 2 || hv.reg_ratio == 4 || hv.reg_ratio == 8) && hv.reg_b - hv.reg_a >= 16 && hv.reg_a <= 16 &&
-                     size.height - (hv.reg_a + (hv.reg_b - hv.reg_a) / 16 * 16) <= 48;
+                     size.height - (hv.reg_a + (hv.reg_b - hv.reg_a) / 4 * 4) <= 48;
             return t;
         }
     }

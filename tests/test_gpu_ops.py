@@ -161,6 +161,43 @@ def test_resize_bit_exact_many_tiles(kc, orc, filt, src, dst):
     assert bit_equal(got, want), "%s %s->%s max ulp %s" % (filt, src, dst, max_ulp(got, want))
 
 
+# Integer-ratio down-sampling (resize_poly_kernel): every filter family (2, 4 and 6 "ages"), ratios 2, 4 and 8, different
+# ratios on the two axes, several bands and strips, heights whose regular rows fill neither a band nor a group of four,
+# widths that are not multiples of 4, and non-finite samples that must stay inside their windows.
+@pytest.mark.parametrize("filt,src,dst", [
+    ("Triangle", (1024, 1024), (256, 256)),
+    ("CatmullRom", (1024, 1024), (256, 256)),
+    ("Lanczos3", (1024, 1024), (256, 256)),
+    ("Gaussian", (1024, 1016), (512, 508)),
+    ("Lanczos3", (1000, 2064), (125, 258)),
+    ("Triangle", (2050, 520), (1025, 65)),       # ratio 2 across, 8 down
+    ("CatmullRom", (516, 2056), (129, 257)),     # ratio 4 across, 8 down
+    ("Gaussian", (2048, 200), (512, 50)),
+    ("Lanczos3", (4093, 236), (1025, 118)),      # not an integer ratio across: general horizontal taps, regular vertical ones
+    ("Lanczos3", (256, 256), (64, 64)),
+])
+def test_resize_integer_ratio_bands(kc, orc, filt, src, dst):
+    (sw, sh), (dw, dh) = src, dst
+    p = splitmix_plane(SEED_A, 3, sh, sw) * np.float32(1.5) - np.float32(0.25)
+    p[sh // 2, sw // 3:sw // 3 + 4] = [np.nan, np.inf, -np.inf, -0.0]
+    p[0, 0] = -np.inf
+    p[-1, -1] = np.inf
+    got = kc.resize_image(kc.SlotImage.from_planes([p]), (dw, dh), kc.ResizeFilter.parse(filt)).planes()[0]
+    want = orc.resize_plane(p, dw, dh, filt)
+    assert bit_equal(got, want), "%s %s->%s max ulp %s" % (filt, src, dst, max_ulp(got, want))
+    assert np.isnan(got).sum() == np.isnan(want).sum() > 0
+
+
+def test_resize_integer_ratio_rgba_one_launch(kc, orc):
+    planes = [splitmix_plane(SEED_B, c, 1040, 772) for c in range(4)]
+    l0 = kc.stats()["kernel_launches"]
+    got = kc.resize_image(kc.SlotImage.from_planes(planes), (193, 260), kc.ResizeFilter.Lanczos3)
+    got.materialize()
+    assert kc.stats()["kernel_launches"] - l0 == 1
+    for c, g in enumerate(got.planes()):
+        assert bit_equal(g, orc.resize_plane(planes[c], 193, 260, "Lanczos3")), c
+
+
 @pytest.mark.parametrize("fusion", [True, False])
 def test_resize_rgba_planes_share_one_launch(kc, orc, fusion):
     """The planes of an image are resampled by one launch (blockIdx.z = plane); aliased planes once."""
