@@ -56,10 +56,13 @@ inline size_t resize_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t v_stride,
     if (h_stride > KC_RESIZE_REG_TAPS) n += 2u * tile_w + (size_t)tile_w * h_stride;
     return n * sizeof(float);
 }
-// resize_down_kernel: swizzled intermediate rows + the tile's horizontal taps at an odd pitch
+// resize_down_kernel / resize_poly_kernel: intermediate rows of a fixed pitch (a window of at most 256 floats, one float of
+// padding after every 32), then the tile's horizontal taps at an odd pitch
+#define KC_DOWN_ROW_FLOATS 265u
 inline size_t resize_down_lds_bytes(uint32_t tile_h, uint32_t ncp, uint32_t tile_w, uint32_t h_stride)
 {
-    return ((size_t)tile_h * ((size_t)ncp + (ncp >> 5) + 1u) + 2u * tile_w + (size_t)tile_w * (h_stride | 1u)) * sizeof(float);
+    (void)ncp;  // <= 256 (host-checked)
+    return ((size_t)tile_h * KC_DOWN_ROW_FLOATS + 2u * tile_w + (size_t)tile_w * (h_stride | 1u)) * sizeof(float);
 }
 // Up to 4 planes of equal size (the planes of one image) resampled by one launch, blockIdx.z = plane.
 struct ResizePlanes {

@@ -805,7 +805,7 @@ static __device__ __forceinline__ DownStrip resize_down_stage(float *lds, const 
     S.tw = x1 - S.x0;
     S.c0 = H.left[S.x0] & ~3u;
     S.nq = (H.left[x1 - 1] + H.count[x1 - 1] - S.c0 + 3u) / 4u;  // <= ncp / 4 (host-checked)
-    S.row_floats = ncp + (ncp >> 5) + 1u;
+    S.row_floats = KC_DOWN_ROW_FLOATS;  // a constant: the horizontal pass addresses its four rows with immediate offsets
     S.hsp = H.stride | 1u;  // odd pitch: the lanes' weight rows start on different banks
     S.tmp = lds;
     S.hl = reinterpret_cast<uint32_t *>(lds + tmp_rows * S.row_floats);
@@ -828,45 +828,53 @@ static __device__ __forceinline__ void resize_down_hrows(const DownStrip &S, con
 {
     const uint32_t n = S.hn[lane], h0 = S.hl[lane];
     const float *w = S.hw + lane * S.hsp;
-    float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    // rows 0, 1 and rows 2, 3 as pairs: one packed multiply and add per pair and tap
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 t01 = { 0.0f, 0.0f }, t23 = { 0.0f, 0.0f };
     // Every column of the strip has the same number of taps, a multiple of 4 (the interior of an integer-ratio resample):
     // no tap needs clamping or masking.
     const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
     if ((nu & 3u) == 0u && __builtin_amdgcn_ballot_w64(n != nu) == 0ull) {
         for (uint32_t j0 = 0; j0 < nu; j0 += 4u) {
-            float p[4][4], wt[4];
+            f2 p01[4], p23[4];
+            float wt[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t idx = h0 + j0 + u;
-                const uint32_t sidx = idx + (idx >> 5);
+                const float *v = row + idx + (idx >> 5);
                 wt[u] = w[j0 + u];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[u][r] = row[r * S.row_floats + sidx];
+                p01[u] = f2{ v[0], v[KC_DOWN_ROW_FLOATS] };
+                p23[u] = f2{ v[2 * KC_DOWN_ROW_FLOATS], v[3 * KC_DOWN_ROW_FLOATS] };
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] += p[u][r] * wt[u];
+            for (int u = 0; u < 4; ++u) {
+                t01 += p01[u] * wt[u];
+                t23 += p23[u] * wt[u];
+            }
         }
-    } else
-    for (uint32_t j0 = 0; j0 < n; j0 += 4u) {
-        float p[4][4], wt[4];
+    } else {
+        for (uint32_t j0 = 0; j0 < n; j0 += 4u) {
+            f2 p01[4], p23[4];
+            float wt[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t jj = min(j0 + u, n - 1u);
-            const uint32_t idx = h0 + jj;
-            const uint32_t sidx = idx + (idx >> 5);
-            wt[u] = w[jj];
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t jj = min(j0 + u, n - 1u);
+                const uint32_t idx = h0 + jj;
+                const float *v = row + idx + (idx >> 5);
+                wt[u] = w[jj];
+                p01[u] = f2{ v[0], v[KC_DOWN_ROW_FLOATS] };
+                p23[u] = f2{ v[2 * KC_DOWN_ROW_FLOATS], v[3 * KC_DOWN_ROW_FLOATS] };
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[u][r] = row[r * S.row_floats + sidx];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool live = j0 + u < n;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] += live ? p[u][r] * wt[u] : -0.0f;
+            for (int u = 0; u < 4; ++u) {
+                // a tap that does not exist contributes -0.0, which leaves every sum unchanged
+                const bool live = j0 + u < n;
+                t01 += live ? p01[u] * wt[u] : f2{ -0.0f, -0.0f };
+                t23 += live ? p23[u] * wt[u] : f2{ -0.0f, -0.0f };
+            }
         }
     }
+    const float t[4] = { t01.x, t01.y, t23.x, t23.y };
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if ((uint32_t)r < nrows) dst_row[(size_t)r * dpitch + S.x0 + lane] = clamp01_nan_passthrough(t[r]);
@@ -1139,7 +1147,7 @@ hipError_t launch_resize_down(const ResizePlanes &p, int batch, uint32_t dw, uin
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (batch < 1 || batch > 4) return hipErrorInvalidValue;
-    if (tile_w == 0 || tile_w > 64 || (tile_h != 16 && tile_h != 32) || ncp % 4 != 0) return hipErrorInvalidValue;
+    if (tile_w == 0 || tile_w > 64 || (tile_h != 16 && tile_h != 32) || ncp % 4 != 0 || ncp > 256) return hipErrorInvalidValue;
     const size_t lds = resize_down_lds_bytes(tile_h, ncp, tile_w, h.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, (dh + tile_h - 1) / tile_h, batch);
     if (tile_h == 16)
@@ -1164,7 +1172,7 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (batch < 1 || batch > 4) return hipErrorInvalidValue;
-    if (tile_w == 0 || tile_w > 64 || ncp % 4 != 0 || reg_a > reg_b || reg_b > dh) return hipErrorInvalidValue;
+    if (tile_w == 0 || tile_w > 64 || ncp % 4 != 0 || ncp > 256 || reg_a > reg_b || reg_b > dh) return hipErrorInvalidValue;
     if ((ages != 2 && ages != 4 && ages != 6) || (ratio != 2 && ratio != 4 && ratio != 8)) return hipErrorInvalidValue;
     PolyBands b{};
     b.ya = reg_a;

@@ -314,7 +314,7 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
         const uint32_t rows = c.resize_tile_h == 32 ? 32u : 16u;  // KC_RESIZE_TILE_H=32: tuning
         for (uint32_t tw = 64; tw >= 4; tw -= 4) {
             const uint32_t groups = tile_groups(th.host, size.width, tw);
-            if (groups > 64 && tw > 4) continue;
+            if (groups > 64) continue;  // the intermediate rows hold 256 floats
             if (resize_down_lds_bytes(rows, 4u * groups, tw, th.dev.stride) > 64 * 1024) continue;
             t.tile_w = tw;
             t.tile_h = rows;
