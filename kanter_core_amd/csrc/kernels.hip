@@ -1485,21 +1485,26 @@ static __device__ __forceinline__ uint32_t quant_u8(float v)
     return (uint32_t)x;               // 0 <= x <= 255: truncation
 }
 
-static __device__ __forceinline__ float srgb_to_linear(float s, const PowCtx *tab)
-{
-    if (s <= 0.0f) return s;
-    if (s <= 0.04045f) return s / 12.92f;
-    return kc_powf((s + 0.055f) / 1.055f, 2.4f, tab);
-}
+// to_u8_srgb as a step function.  q(x) = ((srgb_to_linear(x.clamp(0, 1)) * 255.).min(255.)) as u8 is non-decreasing in x, so
+// q(x) = #{v : x >= T[v]} with T[v] the smallest float that exports as >= v.  The table (srgb_thresholds.inc) is generated
+// with libm's powf -- what the reference's f32::powf calls -- and the identity is checked there for every float in [0, 1]
+// (tools/gen_srgb_thresholds.c), so this form returns exactly what the reference's power does, without computing one: a
+// hardware log2 / exp2 estimate lands within a level of the answer and two table comparisons settle it.
+#include "srgb_thresholds.inc"
 
-static __device__ __forceinline__ uint32_t quant_u8_srgb(float v, const PowCtx *tab)
+static __device__ __forceinline__ uint32_t quant_u8_srgb(float v, const uint32_t *T)
 {
     float x = v;
     if (x < 0.0f) x = 0.0f;
     if (x > 1.0f) x = 1.0f;
-    x = srgb_to_linear(x, tab) * 255.0f;
-    if (!(x <= 255.0f)) x = 255.0f;
-    return (uint32_t)x;
+    if (x != x) return 255u;  // NaN survives the clamp and the power; f32::min(255.) then returns 255
+    const uint32_t xb = __float_as_uint(x);  // non-negative floats order like their bit patterns
+    if ((int32_t)xb <= 0) return 0u;         // +0.0, and -0.0 (which passes the clamp): srgb_to_linear returns s itself
+    const float est = 255.0f * __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf((x + 0.055f) * (1.0f / 1.055f)));
+    uint32_t q = xb < T[1] ? 0u : (uint32_t)fminf(est, 255.0f);
+    while (q < 255u && xb >= T[q + 1u]) ++q;
+    while (q > 0u && xb < T[q]) --q;
+    return q;
 }
 
 static __device__ __forceinline__ float4 load_operand4(const Operand &o, uint32_t row, uint32_t q)
@@ -1512,10 +1517,12 @@ template <bool SRGB>
 __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operand b, Operand a, int gray, uint32_t w,
                                                     uint32_t h, uint8_t *__restrict__ dst)
 {
-    __shared__ double pow_lds[SRGB ? KC_POW_TABLE_DOUBLES : 1];
-    PowCtx pw{};
-    if constexpr (SRGB) pw = pow_setup(pow_lds);
-    const PowCtx *pow_tab = &pw;
+    __shared__ uint32_t srgb_t[SRGB ? 256 : 1];
+    if constexpr (SRGB) {
+        srgb_t[threadIdx.x] = kSrgbThresholdBits[threadIdx.x];  // 256 threads
+        __syncthreads();
+    }
+    const uint32_t *pow_tab = srgb_t;
     const uint32_t row_units = (w + 3) / 4;
     const uint32_t total = row_units * h;
     for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {

@@ -126,10 +126,11 @@ def test_height_to_normal_4096_vs_oracle(kc, orc):
     assert_planes(got, [nx, ny, nz, np.ones_like(p)], what="h2n 4096")
 
 
-def test_to_u8_4096_vs_oracle(kc, orc, planes4096):
+@pytest.mark.parametrize("srgb", [False, True])
+def test_to_u8_4096_vs_oracle(kc, orc, planes4096, srgb):
     a, _ = planes4096
-    got = kc.SlotImage.from_planes(a).to_u8()
-    assert np.array_equal(got, orc.to_u8(orc.Image(a)))
+    got = kc.SlotImage.from_planes(a).to_u8(srgb)
+    assert np.array_equal(got, orc.to_u8(orc.Image(a), srgb))
 
 
 # Down-sampling on both axes at full size (resize_down_kernel: ~1 200 tiles, partial last tiles in both directions,

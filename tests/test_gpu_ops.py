@@ -1,5 +1,7 @@
 """GPU parity, level 2: each HIP kernel against the CPU oracle at f32 on seeded synthetic planes
 (with IEEE edge cases spliced in), through the C ABI operator entry points."""
+import os
+
 import numpy as np
 import pytest
 
@@ -302,14 +304,30 @@ def test_to_u8(kc, orc, shape, srgb):
     planes = [with_edge_cases(p * np.float32(1.2) - np.float32(0.1), 1) for p in synthetic_rgba(SEED_B, h, w)]
     got = kc.SlotImage.from_planes(planes).to_u8(srgb)
     want = orc.to_u8(orc.Image(planes), srgb)
-    if srgb:
-        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1  # powf(2.4) within 1 ulp
-        assert (got != want).mean() < 1e-3
-    else:
-        assert np.array_equal(got, want)
+    # sRGB too: the export is evaluated as a step function whose thresholds come from libm's powf (tools/gen_srgb_thresholds.c)
+    assert np.array_equal(got, want)
     gg = kc.SlotImage.from_planes(planes[:1]).to_u8(srgb)
     wg = orc.to_u8(orc.Image(planes[:1]), srgb)
-    assert np.abs(gg.astype(int) - wg.astype(int)).max() <= (1 if srgb else 0)
+    assert np.array_equal(gg, wg)
+
+
+def test_to_u8_srgb_at_every_threshold(kc, orc):
+    """Every float within 8 ulps of each of the 255 level thresholds, 2^22 other floats of [0, 1] and the special values."""
+    import re
+    inc = open(os.path.join(os.path.dirname(__file__), "..", "kanter_core_amd", "csrc", "srgb_thresholds.inc")).read()
+    T = np.array([int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", inc)], dtype=np.int64)
+    assert T.size == 256 and (np.diff(T[1:]) > 0).all()
+    near = (T[1:, None] + np.arange(-8, 9)[None, :]).reshape(-1)
+    rng = np.random.default_rng(11)
+    rand = rng.integers(0, 0x3F800001, 1 << 22)
+    special = np.array([0, 0x80000000, 0x3F800000, 0x3F800001, 0x7F800000, 0xFF800000, 0x7FC00000, 1, 0x00800000, 0xBF800000], dtype=np.int64)
+    bits = np.concatenate([near, rand, special]).astype(np.uint32)
+    pad = (-bits.size) % 1024
+    bits = np.concatenate([bits, np.zeros(pad, np.uint32)])
+    x = bits.view(np.float32).reshape(-1, 1024)
+    got = kc.SlotImage.from_planes([x]).to_u8(True)
+    want = orc.to_u8(orc.Image([x]), True)
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("channels", [1, 2, 3, 4])
