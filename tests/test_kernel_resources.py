@@ -61,6 +61,7 @@ def test_lean_chain_kernels_keep_full_occupancy(usage):
 
 
 def test_resize_kernels_fit_their_budgets(usage):
-    for frag in ("resize_lds_kernelILi2ELi3EEE", "resize_chain_kernelILi2ELi3EEE"):
+    for frag in ("resize_lds_kernelILi2ELi3EEE", "resize_chain_kernelILi2ELi3EEE", "resize_down_kernelILi4EEE",
+                 "resize_poly_kernelILi6ELi4EEE", "resize_poly_kernelILi6ELi8EEE", "resize_poly_kernelILi2ELi8EEE"):
         (u,) = find(usage, frag)
         assert u["VGPRs"] <= 128, (frag, u)
