@@ -1177,11 +1177,13 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     PolyBands b{};
     b.ya = reg_a;
     b.yb = reg_a + (reg_b - reg_a) / 4u * 4u;
-    // Band height: 12 rows.  Measured on one box (profiles/r02_down_kernel.md): 8 / 12 / 16 rows give 28.7 / 24.5 / 27.7 us on
-    // Lanczos3 4:1 -- shorter bands re-read more of their neighbours' windows, taller ones leave too few waves to overlap
-    // one wave's arithmetic with another's loads; bands sized for one wave per SIMD (20+ rows) were slower still.
-    static const uint32_t rows = std::getenv("KC_POLY_ROWS") ? std::max(4u, (uint32_t)std::atoi(std::getenv("KC_POLY_ROWS")) / 4u * 4u) : 12u;
-    b.rows = rows;
+    // Band height: 12 rows for one plane, 24 for several planes of a long-windowed filter.  Measured on one box
+    // (profiles/r02_down_kernel.md): 8 / 12 / 16 rows give 28.7 / 24.5 / 27.7 us on Lanczos3 4:1 -- shorter bands re-read more
+    // of their neighbours' windows, taller ones leave too few waves to overlap one wave's arithmetic with another's loads
+    // (bands sized for one wave per SIMD, 20+ rows, were slower still); with four planes per launch the waves are there and
+    // 12 / 24 / 36 / 48 rows give 80.5 / 71.2 / 74.8 / 85.4 us.
+    static const uint32_t rows_env = std::getenv("KC_POLY_ROWS") ? std::max(4u, (uint32_t)std::atoi(std::getenv("KC_POLY_ROWS")) / 4u * 4u) : 0u;
+    b.rows = rows_env ? rows_env : (batch >= 2 && ages >= 4) ? 24u : 12u;
     b.n_bands = (b.yb - b.ya + b.rows - 1) / b.rows;
     b.nyb = (b.n_bands + 3u) / 4u;
     // what is left: rows above the first band and below the last one, as general tiles of at most 16 rows
