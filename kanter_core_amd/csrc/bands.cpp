@@ -410,12 +410,11 @@ int evaluate_source(Walk &W, const Node &n)
     }
     // Image / Input*: through the ordinary evaluator (whole image), then the needed rows
     KC_TRY(lg.ensure_clean(n.node_id));
-    for (auto &sd : lg.slot_datas)
-        if (sd.node_id == n.node_id) {
-            kc_image *img = nullptr;
-            KC_TRY(crop_rows(sd.image, 0, sz.height, nd.a, nd.b, &img));
-            W.data[n.node_id].push_back(BandSlot{ sd.slot_id, img, sz.height == 1 ? 0 : nd.a });
-        }
+    for (auto &sd : lg.slots_of(n.node_id)) {
+        kc_image *img = nullptr;
+        KC_TRY(crop_rows(sd.image, 0, sz.height, nd.a, nd.b, &img));
+        W.data[n.node_id].push_back(BandSlot{ sd.slot_id, img, sz.height == 1 ? 0 : nd.a });
+    }
     return KC_OK;
 }
 

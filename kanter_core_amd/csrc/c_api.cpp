@@ -1125,8 +1125,7 @@ int kc_live_graph_node_slot_ids(kc_live_graph *lg, uint32_t node, uint32_t *slot
 try {
     LG_LOCK(lg);
     std::vector<uint32_t> v;
-    for (auto &sd : lg->slot_datas)
-        if (sd.node_id == node) v.push_back(sd.slot_id);
+    for (auto &sd : lg->slots_of(node)) v.push_back(sd.slot_id);
     return copy_ids(v, slots, cap, count);
 }
 KC_CATCH

@@ -137,6 +137,33 @@ const GraphIndex &NodeGraph::index() const
     return idx;
 }
 
+// Appending a node or an edge to a graph whose index is current patches the index instead of invalidating it: building
+// an n-node chain through add_node / connect used to rebuild the whole index n times (a 20 000-node chain took two minutes).
+bool NodeGraph::index_is_current() const
+{
+    return idx.version == version && idx.n_nodes == nodes.size() && idx.n_edges == edges.size();
+}
+
+void NodeGraph::appended_node(bool index_was_current)
+{
+    touch();
+    if (!index_was_current) return;
+    idx.node_pos.emplace(nodes.back().node_id, (uint32_t)(nodes.size() - 1));  // first wins, as in index()
+    idx.version = version;
+    idx.n_nodes = nodes.size();
+}
+
+void NodeGraph::appended_edge(bool index_was_current)
+{
+    touch();
+    if (!index_was_current) return;
+    const kc_edge &e = edges.back();
+    idx.in_edges[e.input_id].push_back(e);
+    idx.out_edges[e.output_id].push_back(e);
+    idx.version = version;
+    idx.n_edges = edges.size();
+}
+
 static const std::vector<kc_edge> kNoEdges;
 
 const std::vector<kc_edge> &NodeGraph::edges_into(uint32_t id) const
@@ -216,8 +243,9 @@ static int add_node_internal(NodeGraph &g, Node n, uint32_t id)
         n.text = avoid_name_collision(names, n.text);
     }
     n.node_id = id;
+    const bool cur = g.index_is_current();
     g.nodes.push_back(std::move(n));
-    g.touch();
+    g.appended_node(cur);
     return KC_OK;
 }
 
@@ -259,10 +287,11 @@ int NodeGraph::try_connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is)
     int t;
     KC_TRY(slot_type_of(node_output_slots(*o), os, &t));
     KC_TRY(slot_type_of(node_input_slots(*i), is, &t));
-    for (auto &e : edges)
-        if (e.input_id == in && e.input_slot == is) return KC_ERR_SLOT_OCCUPIED;
+    for (auto &e : edges_into(in))
+        if (e.input_slot == is) return KC_ERR_SLOT_OCCUPIED;
+    const bool cur = index_is_current();
     edges.push_back(kc_edge{ on, in, os, is });
-    touch();
+    appended_edge(cur);
     return KC_OK;
 }
 
@@ -276,10 +305,11 @@ int NodeGraph::connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is)
     KC_TRY(slot_type_of(node_input_slots(*i), is, &it));
     if (!slot_fits(ot, it)) return KC_ERR_INVALID_SLOT_TYPE;
     (void)disconnect_slot(in, KC_SIDE_INPUT, is, nullptr);
-    for (auto &e : edges)
-        if (e.output_id == on && e.input_id == in && e.output_slot == os && e.input_slot == is) return KC_ERR_INVALID_EDGE;
+    for (auto &e : edges_into(in))
+        if (e.output_id == on && e.output_slot == os && e.input_slot == is) return KC_ERR_INVALID_EDGE;
+    const bool cur = index_is_current();
     edges.push_back(kc_edge{ on, in, os, is });
-    touch();
+    appended_edge(cur);
     return KC_OK;
 }
 
@@ -320,6 +350,13 @@ int NodeGraph::disconnect_slot(uint32_t id, int side, uint32_t slot, std::vector
 {
     // :496-515 (every edge on the slot goes)
     if (!find(id)) return KC_ERR_INVALID_NODE_ID;
+    {
+        // nothing on the slot (the usual case when a graph is being built): the index knows without a scan of every edge
+        bool occupied = false;
+        for (auto &e : side == KC_SIDE_INPUT ? edges_into(id) : edges_out_of(id))
+            occupied = occupied || (side == KC_SIDE_INPUT ? e.input_slot : e.output_slot) == slot;
+        if (!occupied) return KC_ERR_SLOT_NOT_OCCUPIED;
+    }
     bool any = false;
     for (size_t i = edges.size(); i-- > 0;) {
         const kc_edge &e = edges[i];
@@ -455,11 +492,10 @@ static int process_graph_node(kc_live_graph &parent, const Node &node, const Slo
     }
     for (uint32_t oid : child.g.output_ids()) {
         KC_TRY(child.await_clean(oid));
-        for (auto &sd : child.slot_datas)
-            if (sd.node_id == oid) {
-                image_retain(sd.image);
-                out.push_back(SlotData{ node.node_id, oid, sd.image });
-            }
+        for (auto &sd : child.slots_of(oid)) {
+            image_retain(sd.image);
+            out.push_back(SlotData{ node.node_id, oid, sd.image });
+        }
     }
     return KC_OK;
 }
@@ -682,24 +718,31 @@ kc_live_graph::~kc_live_graph()
 
 void kc_live_graph::clear_data()
 {
-    for (auto &sd : slot_datas) image_release(sd.image);
+    for (auto &kv : slot_datas)
+        for (auto &sd : kv.second) image_release(sd.image);
     slot_datas.clear();
 }
 
 void kc_live_graph::remove_nodes_data(uint32_t id)
 {
-    // :353-359
-    for (size_t i = slot_datas.size(); i-- > 0;)
-        if (slot_datas[i].node_id == id) {
-            image_release(slot_datas[i].image);
-            slot_datas.erase(slot_datas.begin() + (long)i);
-        }
+    // :539-548
+    auto it = slot_datas.find(id);
+    if (it == slot_datas.end()) return;
+    for (auto &sd : it->second) image_release(sd.image);
+    slot_datas.erase(it);
+}
+
+const kc::SmallVec<kc::SlotData, 4> &kc_live_graph::slots_of(uint32_t node) const
+{
+    static const kc::SmallVec<kc::SlotData, 4> none{};
+    auto it = slot_datas.find(node);
+    return it == slot_datas.end() ? none : it->second;
 }
 
 const SlotData *kc_live_graph::find_slot(uint32_t node, uint32_t slot) const
 {
-    for (auto &sd : slot_datas)
-        if (sd.node_id == node && sd.slot_id == slot) return &sd;
+    for (auto &sd : slots_of(node))
+        if (sd.slot_id == slot) return &sd;
     return nullptr;
 }
 
@@ -873,7 +916,7 @@ int kc_live_graph::process_one(uint32_t id)
             }
         }
     remove_nodes_data(id);
-    for (auto &sd : outs) slot_datas.push_back(sd);
+    for (auto &sd : outs) slot_datas[sd.node_id].push_back(sd);
     if (!use_cache) {
         // engine.rs:58-75: a parent's planes are dropped once every child of it is Clean or Processing
         // (edge lists straight from the index: a parent or child seen twice changes nothing)
@@ -970,8 +1013,7 @@ int kc_live_graph::await_clean(uint32_t id)
     if (auto_update) KC_TRY(update());
     KC_TRY(ensure_clean(id));
     // Clean means computed: whatever the node still holds is brought into HBM now.
-    for (auto &sd : slot_datas)
-        if (sd.node_id == id) KC_TRY(image_force(sd.image));
+    for (auto &sd : slots_of(id)) KC_TRY(image_force(sd.image));
     return KC_OK;
 }
 
@@ -994,7 +1036,6 @@ int kc_live_graph::update()
         KC_TRY(ensure_clean(id));
     }
     for (uint32_t id : requested)
-        for (auto &sd : slot_datas)
-            if (sd.node_id == id) KC_TRY(image_force(sd.image));
+        for (auto &sd : slots_of(id)) KC_TRY(image_force(sd.image));
     return KC_OK;
 }

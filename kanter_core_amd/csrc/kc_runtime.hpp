@@ -366,6 +366,9 @@ struct NodeGraph {
 
     void touch() { ++version; }
     const GraphIndex &index() const;
+    bool index_is_current() const;
+    void appended_node(bool index_was_current);  // after nodes.push_back: bumps the version, patches a current index
+    void appended_edge(bool index_was_current);  // after edges.push_back
     const std::vector<kc_edge> &edges_into(uint32_t id) const;
     const std::vector<kc_edge> &edges_out_of(uint32_t id) const;
 
@@ -458,6 +461,11 @@ public:
         p_[n_++] = v;
     }
     void clear() { n_ = 0; }
+    void erase_at(size_t i)
+    {
+        std::memmove(static_cast<void *>(p_ + i), p_ + i + 1, (n_ - i - 1) * sizeof(T));
+        --n_;
+    }
     size_t size() const { return n_; }
     bool empty() const { return n_ == 0; }
     T *data() { return p_; }
@@ -490,7 +498,10 @@ struct kc_tex_pro {
 struct kc_live_graph {
     kc_tex_pro *tp = nullptr;
     kc::NodeGraph g;
-    std::deque<kc::SlotData> slot_datas;
+    // by producing node, slots in the order the node returned them (a linear list made every look-up and every
+    // replacement a scan of all cached slots: quadratic with use_cache on a long graph)
+    std::unordered_map<uint32_t, kc::SmallVec<kc::SlotData, 4>> slot_datas;
+    const kc::SmallVec<kc::SlotData, 4> &slots_of(uint32_t node) const;
     std::vector<kc::EmbeddedSlotData> embedded;
     std::vector<kc::SlotData> input_slot_datas;
     std::unordered_map<uint32_t, int> node_state;  // looked up a dozen times per node and evaluation

@@ -257,13 +257,14 @@ int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy
 int kc_live_graph::import_slot_data(uint32_t node, uint32_t slot, kc_image *image)
 {
     if (!g.find(node)) return KC_ERR_INVALID_NODE_ID;
-    for (size_t i = slot_datas.size(); i-- > 0;)
-        if (slot_datas[i].node_id == node && slot_datas[i].slot_id == slot) {
-            image_release(slot_datas[i].image);
-            slot_datas.erase(slot_datas.begin() + (long)i);
+    auto &mine = slot_datas[node];
+    for (size_t i = mine.size(); i-- > 0;)
+        if (mine[i].slot_id == slot) {
+            image_release(mine[i].image);
+            mine.erase_at(i);
         }
     image_retain(image);
-    slot_datas.push_back(SlotData{ node, slot, image });
+    mine.push_back(SlotData{ node, slot, image });
     // new data for this node: whatever was computed from the old one is out of date (the same propagation a
     // connect() triggers, src/live_graph.rs:515-537), the node itself is up to date
     for (uint32_t c : g.get_children(node)) KC_TRY(set_state(c, KC_STATE_DIRTY));

@@ -289,13 +289,18 @@ def test_cycle_in_json_graph_is_reported(live_graph):
 
 
 def test_dirty_propagation_walks_a_very_long_chain_without_recursion(live_graph):
+    # 20 000 nodes: also pins that building a graph is linear (appending a node or an edge patches the look-up index;
+    # rebuilding it per connect() made this take two minutes)
+    import time
     lg = live_graph
-    n = 2000
+    n = 20000
+    t0 = time.perf_counter()
     ids = [lg.add_node(_mix())]
     for _ in range(n):
         nxt = lg.add_node(_mix())
         lg.connect(ids[-1], nxt, SlotId(0), SlotId(0))
         ids.append(nxt)
+    assert time.perf_counter() - t0 < 20.0
     lg.changed_consume()
     lg.connect(ids[0], ids[1], SlotId(0), SlotId(1))
     assert lg.node_state(ids[-1]) == NodeState.Dirty
