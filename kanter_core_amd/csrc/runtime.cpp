@@ -568,6 +568,9 @@ int planes_force(kc_plane *const *planes, int n)
     if (todo.empty()) return KC_OK;  // constants / resident planes: nothing to launch
     KC_TRY(need_init());
     for (auto *p : todo) {
+        // forcing a prefix or an operand below can run another plane of this very list (an image may hold a chain and
+        // its own prefix): it is resident then and has nothing left to flatten
+        if (p->kind != kc_plane::LAZY) continue;
         chain_flatten(p);
         // The input count was bounded when the chain was built, but a constant operand can have been
         // materialised since (kc_plane_materialize, a resize of it ...) and now occupies an input slot.
@@ -585,6 +588,7 @@ int planes_force(kc_plane *const *planes, int n)
         }
         KC_TRY(chain_prepare(p));
     }
+    todo.erase(std::remove_if(todo.begin(), todo.end(), [](kc_plane *q) { return q->kind != kc_plane::LAZY; }), todo.end());
     size_t i = 0;
     while (i < todo.size()) {
         BuiltChain bc;

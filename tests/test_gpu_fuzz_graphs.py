@@ -158,6 +158,21 @@ def test_random_graph_matches_the_oracle(kc, orc, seed):
             assert_planes(g.image.planes(), w.image.planes, what="seed %d node %d slot %d" % (seed, int(n), int(g.slot_id)))
 
 
+@pytest.mark.parametrize("seed", [0xF0990000 + 11057])
+def test_soak_seeds_that_found_defects(kc, orc, seed):
+    """Seeds from profiles/soak_fuzz.py.  0xF0990000 + 11057: an image whose planes include a chain AND a plane that chain
+    has to run first (more than KC_CHAIN_MAX_IN inputs): forcing the image forced the prefix through the recursion and then
+    met it again, resident, in its own work list -- a null dereference in chain_flatten."""
+    _, _, requested = _build(kc, orc, seed)
+    for n in requested:
+        lg, ref, _ = _build(kc, orc, seed)
+        want = ref.node_slot_datas(int(n))
+        got = lg.await_clean(n).node_slot_datas(n)
+        assert len(got) == len(want)
+        for g, w in zip(sorted(got, key=lambda s: s.slot_id), sorted(want, key=lambda s: s.slot_id)):
+            assert_planes(g.image.planes(), w.image.planes, what="seed %x node %d" % (seed, int(n)))
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_random_graph_unfused_and_cached_agree(kc, orc, seed):
     """The same graphs with fusion switched off and with use_cache: every node materialised."""
