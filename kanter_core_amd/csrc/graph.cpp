@@ -997,7 +997,14 @@ int kc_live_graph::ensure_clean(uint32_t root)
             if (pn)
                 for (auto &sl : node_output_slots(*pn)) has_slot |= sl.slot_id == e.output_slot;
             if (!has_slot) return KC_ERR_NO_SLOT_DATA;
-            KC_TRY(set_state(e.output_id, KC_STATE_DIRTY));
+            // Only the parent itself: it is recomputed right below and, planes being a pure function of the graph, yields
+            // the data it had.  The reference's set_state would dirty every descendant too and its engine then recomputes
+            // them; this walk has already passed some of them (another parent of the node on the stack, brought up to
+            // date a moment ago) and would have left them Dirty WITH Clean children -- after which an edit of such a node
+            // (set_mix_type: "already Dirty", no propagation) did not reach its children (profiles/soak_fuzz.py, edit
+            // seeds 210 and 5678).
+            node_state[e.output_id] = KC_STATE_DIRTY;
+            changed.insert(e.output_id);
         }
         f.awaiting = true;
         KC_TRY(enter(e.output_id));  // may invalidate f

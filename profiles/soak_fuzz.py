@@ -74,6 +74,18 @@ for seed in range(graph0, graph0 + n_graphs):
             print("MISMATCH graph seed %x node %d: %s" % (s, int(n), str(e)[:200]), flush=True)
     if seed % 100 == 99:
         print("graphs: %d done, %d mismatches, %.0f s" % (seed + 1, bad, time.time() - t0), flush=True)
-print("soak finished: %d resizes, %d graphs, %d mismatches, %.0f s" % (n_resize, n_graphs, bad, time.time() - t0))
+# the edit / re-evaluate and the fused-vs-unfused-vs-cached tests of the suite, on seeds beyond the suite's
+n_edit = int(os.environ.get("KC_SOAK_EDITS", "0"))
+for seed in range(80, 80 + n_edit):
+    try:
+        fz.test_random_graph_edits_re_evaluate_like_a_fresh_graph(kc, orc, seed)
+        if seed < 80 + n_edit // 4:
+            fz.test_random_graph_unfused_and_cached_agree(kc, orc, 40 + seed)
+    except AssertionError as e:
+        bad += 1
+        print("MISMATCH edit / cache seed %d: %s" % (seed, str(e)[:200]), flush=True)
+    if seed % 500 == 499:
+        print("edits: %d done, %d mismatches, %.0f s" % (seed + 1 - 80, bad, time.time() - t0), flush=True)
+print("soak finished: %d resizes, %d graphs, %d edit sequences, %d mismatches, %.0f s" % (n_resize, n_graphs, n_edit, bad, time.time() - t0))
 kc.shutdown()
 sys.exit(1 if bad else 0)

@@ -260,6 +260,14 @@ def test_random_graph_edits_re_evaluate_like_a_fresh_graph(kc, orc, seed):
             return
 
 
+@pytest.mark.parametrize("seed", [210, 5678])
+def test_soak_edit_seeds_that_found_defects(kc, orc, seed):
+    """A source whose data had been dropped (use_cache == false) was re-dirtied WITH its descendants in the middle of a
+    walk that had already passed some of them: they stayed Dirty above Clean children, and a later set_mix_type on one of
+    them ("already Dirty") did not propagate -- the requested node kept its old pixels."""
+    test_random_graph_edits_re_evaluate_like_a_fresh_graph(kc, orc, seed)
+
+
 @pytest.mark.parametrize("seed", range(200))
 def test_random_resizes_match_the_oracle(kc, orc, seed):
     """Random source and target extents (1 .. ~700, log-uniform, independent per axis) and filters: tile edges,
