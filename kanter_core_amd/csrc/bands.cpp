@@ -61,6 +61,7 @@ struct Walk {
     kc_live_graph &lg;
     std::vector<uint32_t> topo;
     std::map<uint32_t, kc_size> size;
+    std::map<uint32_t, bool> rgba;  // type of the node's output(s): some operators' output SIZE depends on it (Separate of a gray image)
     std::map<uint32_t, Need> need;
     std::map<uint32_t, std::vector<BandSlot>> data;
     explicit Walk(kc_live_graph &g) : lg(g) {}
@@ -103,6 +104,22 @@ int topo_order(const NodeGraph &g, uint32_t root, std::vector<uint32_t> &topo)
 }
 
 bool is_source(const Node &n) { return n.type == KC_NODE_EMBED || n.type == KC_NODE_IMAGE || n.is_input(); }
+
+// Is a source node's image RGBA?  (Image nodes are: image_from_u8 always builds four planes.)
+bool source_is_rgba(Walk &W, const Node &n)
+{
+    kc_live_graph &lg = W.lg;
+    if (n.type == KC_NODE_EMBED) {
+        for (auto &e : lg.embedded)
+            if (e.slot_data_id == n.embed_id) return e.image->is_rgba();
+        return false;
+    }
+    if (n.type == KC_NODE_IMAGE) return true;
+    if (n.type == KC_NODE_INPUT_RGBA) return !lg.input_slot_datas.empty() && lg.input_slot_datas[0].image->is_rgba();
+    for (auto &in : lg.input_slot_datas)
+        if (in.node_id == n.node_id) return in.image->is_rgba();
+    return false;
+}
 
 // ---- (2) sizes -------------------------------------------------------------------------------------------
 int source_size(Walk &W, const Node &n, kc_size *out)
@@ -174,8 +191,10 @@ int infer_sizes(Walk &W)
     for (uint32_t id : W.topo) {
         const Node &n = *g.find(id);
         kc_size s{ 1, 1 };
+        bool rgba = false;
         if (is_source(n)) {
             KC_TRY(source_size(W, n, &s));
+            rgba = source_is_rgba(W, n);
         } else if (n.type == KC_NODE_VALUE) {
             s = kc_size{ 1, 1 };
         } else if (n.type == KC_NODE_GRAPH || n.type == KC_NODE_WRITE) {
@@ -192,8 +211,42 @@ int infer_sizes(Walk &W)
             } else {
                 KC_TRY(target_size(W, n, edges, &s));
             }
+            // the operators' own rules (csrc/ops.cpp), as far as they decide the size or the type of what comes out
+            auto parent_on = [&](uint32_t slot) -> const kc_edge * {
+                for (auto &e : edges)
+                    if (e.input_slot == slot) return &e;
+                return nullptr;
+            };
+            switch (n.type) {
+            case KC_NODE_MIX: {
+                const kc_edge *l = parent_on(0), *r = parent_on(1);
+                rgba = l ? W.rgba[l->output_id] : r ? W.rgba[r->output_id] : false;  // as_type(right, left's type)
+                break;
+            }
+            case KC_NODE_SEPARATE_RGBA: {
+                // slot_datas.get(0): the input on the lowest connected slot; a gray (or missing) one gives four 1x1 zeros
+                const kc_edge *first = nullptr;
+                for (auto &e : edges)
+                    if (!first || e.input_slot < first->input_slot) first = &e;
+                if (!first || !W.rgba[first->output_id]) s = kc_size{ 1, 1 };
+                rgba = false;
+                break;
+            }
+            case KC_NODE_COMBINE_RGBA:
+            case KC_NODE_HEIGHT_TO_NORMAL: rgba = true; break;
+            case KC_NODE_OUTPUT_GRAY:
+            case KC_NODE_OUTPUT_RGBA: {
+                const kc_edge *first = nullptr;
+                for (auto &e : edges)
+                    if (!first || e.input_slot < first->input_slot) first = &e;
+                rgba = first ? W.rgba[first->output_id] : n.type == KC_NODE_OUTPUT_RGBA;
+                break;
+            }
+            default: break;
+            }
         }
         W.size[id] = s;
+        W.rgba[id] = rgba;
     }
     return KC_OK;
 }

@@ -182,6 +182,15 @@ static int get_band_taps(uint32_t in_n, uint32_t out_n, int filter, int32_t a, i
     auto key = std::make_tuple(in_n, out_n, filter, a, b, src_y0);
     auto it = c.band_taps.find(key);
     if (it != c.band_taps.end()) {
+        // the key does not hold the number of rows the source band has: a table built for a taller band must not be
+        // used on a shorter one without the check below (a kernel reading past the band is a GPU memory fault)
+        uint32_t need_rows = 0;
+        for (size_t i = 0; i < it->second.host.left.size(); ++i)
+            need_rows = std::max(need_rows, it->second.host.left[i] + it->second.host.count[i]);
+        if (need_rows > src_rows) {
+            set_error("resize band: the source band does not hold the rows this output band needs (halo rows missing)");
+            return KC_ERR_INVALID_ARG;
+        }
         *out = &it->second;
         return KC_OK;
     }

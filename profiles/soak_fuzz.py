@@ -74,6 +74,43 @@ for seed in range(graph0, graph0 + n_graphs):
             print("MISMATCH graph seed %x node %d: %s" % (s, int(n), str(e)[:200]), flush=True)
     if seed % 100 == 99:
         print("graphs: %d done, %d mismatches, %.0f s" % (seed + 1, bad, time.time() - t0), flush=True)
+# row bands of random graphs, stacked, against the whole-image evaluation (both by the library; csrc/bands.cpp)
+n_band = int(os.environ.get("KC_SOAK_BANDS", "0"))
+brng = np.random.default_rng(0x50AC0002)
+unsupported = 0
+band0 = int(os.environ.get("KC_SOAK_BAND0", "0"))
+for seed in range(band0, band0 + n_band):
+    sd = 0xF0AA0000 + seed
+    if os.environ.get("KC_SOAK_VERBOSE"):
+        print("band seed", seed, flush=True)
+    _, _, requested = fz._build(kc, orc, sd)
+    for n in requested[:2]:
+        lg, _, _ = fz._build(kc, orc, sd)
+        try:
+            whole = lg.await_clean(n).node_slot_datas(n)
+        except kc.TexProError:
+            continue
+        for w in whole:
+            planes = w.image.planes()
+            h = planes[0].shape[0]
+            cuts = sorted(set([0, h] + [int(c) for c in brng.integers(0, h + 1, size=int(brng.integers(0, 4)))]))
+            lg2, _, _ = fz._build(kc, orc, sd)
+            try:
+                parts = [lg2.evaluate_band(n, y0, y1, int(w.slot_id)).planes() for y0, y1 in zip(cuts[:-1], cuts[1:]) if y1 > y0]
+            except kc.TexProError as e:
+                unsupported += 1
+                if os.environ.get("KC_SOAK_VERBOSE"):
+                    print("   refused:", str(e)[:160], flush=True)
+                continue
+            try:
+                stacked = [np.concatenate([p[c] for p in parts], axis=0) for c in range(len(planes))]
+                assert_planes(stacked, planes, what="bands seed %x node %d slot %d cuts %s" % (sd, int(n), int(w.slot_id), cuts))
+            except (AssertionError, ValueError) as e:
+                bad += 1
+                print("MISMATCH", str(e)[:240], "| whole", [p.shape for p in planes], "parts", [[q.shape for q in p] for p in parts], flush=True)
+    if seed % 500 == 499:
+        print("bands: %d graphs done, %d mismatches, %d band evaluations refused, %.0f s" % (seed + 1, bad, unsupported, time.time() - t0), flush=True)
+
 # the edit / re-evaluate and the fused-vs-unfused-vs-cached tests of the suite, on seeds beyond the suite's
 n_edit = int(os.environ.get("KC_SOAK_EDITS", "0"))
 for seed in range(80, 80 + n_edit):
