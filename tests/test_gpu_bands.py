@@ -177,3 +177,27 @@ def test_band_at_full_size_4096_with_resize_and_h2n(kc):
     whole = lg.await_clean(h2n).slot_data(h2n, 0).image.planes()
     parts = [lg.evaluate_band(h2n, y0, y1).planes() for (y0, y1) in ((0, 2048), (2048, 4096))]
     assert_planes([np.concatenate([p[c] for p in parts], axis=0) for c in range(4)], whole, what="4096 bands")
+
+
+def test_separate_of_a_gray_image_is_1x1_in_bands_too(kc):
+    """SeparateRgba of a gray image returns four 1 x 1 zeros whatever the input's size (separate_rgba.rs:38-69); the band
+    planner used to give them the input's size -- a wrong plan for everything downstream (found by profiles/soak_fuzz.py).
+    Downstream here: a Mix of the separated channel (1 x 1) with a full-size image, resized by the Mix, then HeightToNormal."""
+    h, w = 23, 40
+    imgs = {0: [splitmix_plane(SEED_A, 0, h, w)], 1: [splitmix_plane(SEED_B, 0, h, w)]}
+    g = G()
+    a, b = g.add({"Embed": 0}), g.add({"Embed": 1})
+    sep = g.add("SeparateRgba")
+    g.connect(a, sep, 0, 0)
+    mix = g.add({"Mix": "Add"}, filt="Lanczos3")
+    g.connect(sep, mix, 2, 0)
+    g.connect(b, mix, 0, 1)
+    h2n = g.add("HeightToNormal")
+    g.connect(mix, h2n, 0, 0)
+    _, lg = build(kc, g.dict(), imgs)
+    whole = lg.await_clean(sep).slot_data(sep, 2).image.planes()
+    _, lg2 = build(kc, g.dict(), imgs)
+    band = lg2.evaluate_band(sep, 0, 1, 2).planes()
+    assert [p.shape for p in band] == [p.shape for p in whole] == [(1, 1)]
+    assert_planes(band, whole, what="separate of gray")
+    check_bands(kc, g.dict(), imgs, h2n, "separate of gray -> mix -> h2n")
