@@ -50,10 +50,13 @@ def random_graph(rng):
     return g.dict(), outs[-1][0], outs[-1][1]
 
 
-def worker(rank, world, port, n_graphs, q):
+def worker(rank, world, port, n_graphs, q, device=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import kanter_core_amd as kc
+    if device:
+        import torch
+        kc.init(0)  # every rank on cuda:0: a rehearsal of the RCCL path with planes staged through the host (gloo)
     import test_multi_gpu_gloo as mg
     from kanter_core_amd.multi_gpu import PartitionedEvaluator
     from oracle import oracle as orc
@@ -63,14 +66,30 @@ def worker(rank, world, port, n_graphs, q):
         graph, root, slot = random_graph(rng)
         policy = kc.PartitionPolicy.Spread if gi & 1 else kc.PartitionPolicy.Auto
         emb = mg.embedded_images(orc, graph)
-        lg = mg.host_live_graph(graph)
-        ev = PartitionedEvaluator(lg, root, policy=policy, backend=lambda plan, r: mg.OracleBackend(orc, graph, emb, plan, r))
-        for rep in range(2):
-            ev.backend.ref.results.clear()
+        if device:
+            plan = mg.host_live_graph(graph).partition(root, world, policy)
+            mine = {n for (n, r, _, k) in plan.nodes if r == rank and k == kc.NodeKind.Source}
+            tp = kc.TextureProcessor.new()
+            lg = tp.new_live_graph()
+            lg.set_node_graph(kc.NodeGraph.from_json(json.dumps(graph)))
+            for nd in graph["nodes"]:
+                t = nd["node_type"]
+                if isinstance(t, dict) and "Embed" in t and nd["node_id"] in mine:
+                    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(emb[t["Embed"]].planes)), t["Embed"])
+            ev = PartitionedEvaluator(lg, root, policy=policy, device=torch.device("cuda", 0))
             img = ev.evaluate()
+            got = img.planes() if img is not None else None
+        else:
+            lg = mg.host_live_graph(graph)
+            ev = PartitionedEvaluator(lg, root, policy=policy, backend=lambda plan, r: mg.OracleBackend(orc, graph, emb, plan, r))
+            for rep in range(2):
+                ev.backend.ref.results.clear()
+                img = ev.evaluate()
+            got = img.planes if img is not None else None
         if rank == ev.plan.home:
             want = orc.RefGraph(graph, embedded=emb).slot_data(root, 0).image.planes
-            ok = img is not None and len(img.planes) == len(want) and all(a.tobytes() == b.tobytes() for a, b in zip(img.planes, want))
+            nan_eq = lambda a, b: a.shape == b.shape and bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+            ok = got is not None and len(got) == len(want) and all(nan_eq(np.asarray(a), np.asarray(b)) for a, b in zip(got, want))
             if not ok:
                 bad += 1
                 print("MISMATCH graph %d world %d" % (gi, world), json.dumps(graph)[:800], flush=True)
@@ -86,11 +105,12 @@ if __name__ == "__main__":
     import socket
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    device = len(sys.argv) > 3 and sys.argv[3] == "device"
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     t0 = time.time()
-    procs = [ctx.Process(target=worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, n, q, device)) for r in range(world)]
     for p in procs: p.start()
     res = [q.get(timeout=3000) for _ in range(world)]
     for p in procs: p.join(timeout=60)
