@@ -23,6 +23,12 @@ cp kanter_core_amd/libkanter_core_amd.so $OUT/regular.so
 cp $OUT/libkanter_core_amd.so kanter_core_amd/libkanter_core_amd.so
 trap 'cp $OUT/regular.so kanter_core_amd/libkanter_core_amd.so' EXIT
 if [ "$SAN" = thread ]; then RT=$($CL -print-file-name=libclang_rt.tsan-x86_64.so); else RT=$($CL -print-file-name=libclang_rt.asan-x86_64.so); fi
+if [ -n "${KC_SANITIZE_CMD:-}" ]; then
+  # any command instead of pytest, e.g. KC_SANITIZER=thread KC_SANITIZE_CMD="python profiles/soak_threads.py 4 100"
+  LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+      TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0${KC_TSAN_LOG:+:log_path=$KC_TSAN_LOG} $KC_SANITIZE_CMD
+  exit $?
+fi
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
     TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0${KC_TSAN_LOG:+:log_path=$KC_TSAN_LOG} \
     python -m pytest ${KC_SANITIZE_TESTS:-tests/test_host_graph.py tests/test_host_fuzz.py tests/test_cabi_null_args.py tests/test_cabi_symbols.py tests/test_multi_gpu_gloo.py tests/test_bands_host.py tests/test_specialize_host.py} -x -q "$@"
