@@ -127,11 +127,30 @@ KC_API const char *kc_status_string(int status);
  * fused kernel; 0: every node materialises its planes.  Results are bit-identical either way. */
 KC_API int kc_set_fusion(int enabled);
 KC_API int kc_get_fusion(void);
+/* Which resize kernels may run (an A/B and test knob; results are bit-identical in every mode; env KC_RESIZE_MODE):
+ * 0 (default) all; 1 no resize_poly_kernel; 2 no resize_down_kernel either; 3 two passes through HBM only;
+ * 4 everything except the integer-ratio up-sampling kernels.  Replaces nothing of the reference
+ * (src/shared.rs:159-199 has one code path). */
+KC_API int kc_set_resize_mode(int mode);
+KC_API int kc_get_resize_mode(void);
+/* Diagnostics (host only, works without a device): the structure the integer-ratio up-sampling kernels rely on,
+ * for one axis of image::imageops::resize (src/shared.rs:159-199) from in_n to out_n samples with `filter`.
+ * *eligible = 0: the tap table does not have it (not a whole ratio, an even window ...) and the general kernels run.
+ * Otherwise info = { ratio, taps, off, b_lo, b_hi }: the window of output o is source samples
+ * [o / ratio - off, o / ratio - off + taps) cut to the source; outputs b_lo .. out_n - b_hi - 1 use weight row
+ * o % ratio, the first b_lo and last b_hi outputs rows ratio + o and ratio + b_lo + (o - (out_n - b_hi));
+ * `rows` receives those (ratio + b_lo + b_hi) x taps weights (as many as fit `cap` floats). */
+KC_API int kc_resize_upsample_plan(uint32_t in_n, uint32_t out_n, int filter, int *eligible, int32_t info[5], float *rows,
+                                   size_t cap);
 /* Pool statistics: bytes currently handed out, bytes cached for reuse, kernels launched. */
 KC_API int kc_stats(uint64_t *bytes_in_use, uint64_t *bytes_cached, uint64_t *kernel_launches);
 /* Algorithmic HBM bytes of every kernel launched so far: per launch, each resident input plane read once and each
  * result plane written once (what a roofline divides by; fused intermediates and constant planes cost nothing). */
 KC_API int kc_stats_algorithmic_bytes(uint64_t *bytes);
+/* Named event counters since kc_init (tests and profiling: which kernel family a call went through).  Unknown names
+ * read 0.  Names: "upsample_launches", "upsample_chain_launches" (the integer-ratio up-sampling kernels),
+ * "resize_chain_launches" (the general fused resample + chain kernel). */
+KC_API int kc_stats_counter(const char *name, uint64_t *value);
 KC_API int kc_pool_trim(void);
 /* Run-time specialisation of the fused Mix-chain kernel.  A chain of N Mix nodes (src/node/mix.rs:136-192
  * applied N times) normally runs through a step-table interpreter; a program that keeps coming back is also

@@ -9,6 +9,7 @@ from .api import (Edge, EmbeddedSlotDataId, LiveGraph, MixType, Node, NodeGraph,
                   TextureProcessor, calculate_size, combine_rgba_process, get_stream, height_to_normal_process,
                   init, is_initialized, mix_process, resize_image, separate_rgba_process, set_fusion, set_stream,
                   shutdown, stats, sync, value_process, set_specialize, get_specialize, specialize_wait,
-                  specialize_stats, specialize_compile_check, Partition, PartitionPolicy, NodeKind)
+                  specialize_stats, specialize_compile_check, Partition, PartitionPolicy, NodeKind, set_resize_mode,
+                  get_resize_mode, resize_upsample_plan, stats_counter)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

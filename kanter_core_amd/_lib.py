@@ -54,6 +54,11 @@ SIGNATURES = {
     "kc_last_error": (C.c_char_p, []),
     "kc_status_string": (C.c_char_p, [C.c_int]),
     "kc_set_fusion": (C.c_int, [C.c_int]),
+    "kc_set_resize_mode": (C.c_int, [C.c_int]),
+    "kc_get_resize_mode": (C.c_int, []),
+    "kc_stats_counter": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64)]),
+    "kc_resize_upsample_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_float), C.c_size_t]),
     "kc_get_fusion": (C.c_int, []),
     "kc_stats": (C.c_int, [C.POINTER(C.c_uint64)] * 3),
     "kc_set_specialize": (C.c_int, [C.c_int, C.c_int]),

@@ -87,6 +87,34 @@ def set_fusion(enabled):
     _check(_lib.load().kc_set_fusion(int(bool(enabled))))
 
 
+def set_resize_mode(mode):
+    """0 all resize kernels, 1-3 A/B switches of the down-sampling kernels, 4 no integer-ratio up-sampling kernels."""
+    _check(_lib.load().kc_set_resize_mode(int(mode)))
+
+
+def get_resize_mode():
+    return _lib.load().kc_get_resize_mode()
+
+
+def resize_upsample_plan(in_n, out_n, filter=None):
+    """Host only: the structure the integer-ratio up-sampling kernels rely on for one axis (kc_resize_upsample_plan),
+    as a dict {ratio, taps, off, b_lo, b_hi, rows: float32[ratio + b_lo + b_hi, taps]}, or None when the axis
+    does not have it."""
+    import numpy as np
+    L = _lib.load()
+    f = ResizeFilter.default() if filter is None else filter
+    ok = C.c_int(0)
+    info = (C.c_int32 * 5)()
+    _check(L.kc_resize_upsample_plan(int(in_n), int(out_n), int(f), C.byref(ok), info, None, 0))
+    if not ok.value:
+        return None
+    ratio, taps, off, b_lo, b_hi = (int(v) for v in info)
+    rows = np.zeros(((ratio + b_lo + b_hi), taps), np.float32)
+    _check(L.kc_resize_upsample_plan(int(in_n), int(out_n), int(f), C.byref(ok), info,
+                                     rows.ctypes.data_as(C.POINTER(C.c_float)), rows.size))
+    return dict(ratio=ratio, taps=taps, off=off, b_lo=b_lo, b_hi=b_hi, rows=rows)
+
+
 def set_specialize(mode, after=0):
     """Run-time specialisation of the fused chain kernel: 0 interpreter only, 1 compile in the background once a
     program has been seen `after` times (default), 2 compile at first sight and wait.  Bit-identical results."""
@@ -123,6 +151,13 @@ def stats():
     d = C.c_uint64()
     _check(_lib.load().kc_stats_algorithmic_bytes(C.byref(d)))
     return {"bytes_in_use": a.value, "bytes_cached": b.value, "kernel_launches": c.value, "algorithmic_bytes": d.value}
+
+
+def stats_counter(name):
+    """Named event counter (kc_stats_counter), e.g. "upsample_launches"."""
+    v = C.c_uint64()
+    _check(_lib.load().kc_stats_counter(name.encode(), C.byref(v)))
+    return v.value
 
 
 # ------------------------------------------------------------------ small value types

@@ -197,6 +197,35 @@ KC_CATCH
 
 int kc_get_fusion(void) { return ctx().fusion ? 1 : 0; }
 
+int kc_set_resize_mode(int mode)
+try {
+    KC_ARG(mode >= 0 && mode <= 4);
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    ctx().resize_mode = mode;
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_get_resize_mode(void) { return ctx().resize_mode; }
+
+int kc_resize_upsample_plan(uint32_t in_n, uint32_t out_n, int filter, int *eligible, int32_t info[5], float *rows, size_t cap)
+try {
+    KC_ARG(eligible && info);
+    TapsHost t;
+    KC_TRY(build_taps_host(in_n, out_n, filter, t));
+    *eligible = t.up_ok ? 1 : 0;
+    if (!t.up_ok) return KC_OK;
+    info[0] = (int32_t)t.up.ratio;
+    info[1] = (int32_t)t.up.taps;
+    info[2] = t.up.off;
+    info[3] = (int32_t)t.up.b_lo;
+    info[4] = (int32_t)t.up.b_hi;
+    if (rows)
+        for (size_t i = 0; i < t.up_rows.size() && i < cap; ++i) rows[i] = t.up_rows[i];
+    return KC_OK;
+}
+KC_CATCH
+
 int kc_set_specialize(int mode, int after)
 try {
     KC_ARG(mode >= 0 && mode <= 2);
@@ -255,6 +284,17 @@ try {
     if (in_use) *in_use = c.bytes_in_use;
     if (cached) *cached = c.bytes_cached;
     if (launches) *launches = c.launches;
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_stats_counter(const char *name, uint64_t *value)
+try {
+    KC_ARG(name && value);
+    Context &c = ctx();
+    Lock lk(c.mu);
+    auto it = c.counters.find(name);
+    *value = it == c.counters.end() ? 0 : it->second;
     return KC_OK;
 }
 KC_CATCH

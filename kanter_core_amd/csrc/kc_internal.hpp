@@ -17,6 +17,7 @@
 namespace kc {
 
 #include "chain_program.h"  // ChainCode, ChainStepRec / ChainStepPair, ChainProgram
+#include "upsample.h"       // UpAxis, UpsampleArgs
 
 // Per-axis tap table of the separable resampler, resident in HBM.
 struct TapsDev {
@@ -79,6 +80,29 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
 // Fused resample + chain: input slot n_in - 1 of the program is produced by the resampler.
 hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);
+// Integer-ratio up-sampling (upsample.h).  A workgroup's tile: tile_w columns x KC_UPSAMPLE_ROWS * (1024 / tile_w) rows
+// (every thread 4 columns x KC_UPSAMPLE_ROWS rows, one trip).  LDS: the tile's intermediate, then the H quad classes.
+#ifdef KC_UP_RU  // tuning builds (tools/build_variant.sh)
+constexpr uint32_t KC_UPSAMPLE_ROWS = KC_UP_RU;
+#else
+constexpr uint32_t KC_UPSAMPLE_ROWS = 4;
+#endif
+inline uint32_t upsample_tile_rows(const UpsampleArgs &u) { return KC_UPSAMPLE_ROWS * (1024u / u.tile_w); }
+inline size_t upsample_lds_bytes(const UpsampleArgs &u)
+{
+    return ((size_t)upsample_tile_rows(u) * u.ncp + (size_t)((u.H.ratio >> 2) + u.H.qb_lo + u.H.qb_hi) * 4u * u.H.taps) * sizeof(float);
+}
+// The plane members of ChainProgram that the plain up-sampling kernel reads (K = 1: no resident inputs).
+struct UpsamplePlanes {
+    const float *samp_src[4];
+    unsigned int samp_pitch[4];  // floats
+    float *out[4];
+    unsigned int out_pitch[4];  // float4 units
+    const float *in[4][1];
+    unsigned int in_pitch[4][1];
+};
+hipError_t launch_upsample_chain(const ChainProgram &p, int batch, const UpsampleArgs &u, hipStream_t s);
+hipError_t launch_upsample(const UpsamplePlanes &p, int batch, const UpsampleArgs &u, hipStream_t s);
 hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, uint32_t full_h, int band,
                                    float *nx, float *ny, float *nz, uint32_t opitch, hipStream_t s);
 hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,

@@ -162,6 +162,11 @@ struct TapsHost {
     // Integer-ratio down-sampling: output indices [reg_a, reg_b) all have reg_ages * reg_ratio taps, windows reg_ratio
     // apart and bit-identical weights (resize_poly_kernel); reg_ratio == 0: no such range.
     uint32_t reg_a = 0, reg_b = 0, reg_ages = 0, reg_ratio = 0;
+    // Integer-ratio up-sampling (upsample.h): the table has that structure (up_axis_build checks it bit for bit);
+    // up_rows = the class rows, up.cls points at their copy in HBM once the table is uploaded.
+    bool up_ok = false;
+    UpAxis up{};
+    std::vector<float> up_rows, up_qrows;  // class rows per output / per column quad (tap-major)
 };
 
 struct TapsEntry {
@@ -180,11 +185,12 @@ struct Context {
     bool fusion = true;
     int max_blocks = 4096;
     int chain_unroll = 0;  // float4 per thread per decode in the chain kernel; 0 = heuristic (KC_CHAIN_UNROLL)
-    int resize_mode = 0;  // 0 auto (tiled single pass when a tile fits in LDS), 1 no resize_poly_kernel, 2 no resize_down_kernel either (A/B), 3 two passes through HBM only (KC_RESIZE_MODE)
+    int resize_mode = 0;  // 0 auto (tiled single pass when a tile fits in LDS), 1 no resize_poly_kernel, 2 no resize_down_kernel either (A/B), 3 two passes through HBM only, 4 auto without the integer-ratio up-sampling kernels (KC_RESIZE_MODE, kc_set_resize_mode)
     int resize_tile_w = 0;  // > 0: force this tile width (KC_RESIZE_TILE_W, tuning only)
     int resize_tile_h = 0;  // > 0: force this tile height for 256-wide tiles (KC_RESIZE_TILE_H, tuning only)
     std::multimap<size_t, void *> free_blocks;
     uint64_t bytes_in_use = 0, bytes_cached = 0, launches = 0;
+    std::map<std::string, uint64_t> counters;  // named event counts (kc_stats_counter): which kernel family ran, transfers ...
     uint64_t alg_bytes = 0;  // algorithmic HBM bytes of every kernel launched so far (DESIGN.md section 3's per-kernel figures)
     std::map<std::tuple<uint32_t, uint32_t, int>, TapsEntry> taps;
     std::map<std::tuple<uint32_t, uint32_t, int, int32_t, int32_t, int32_t>, TapsEntry> band_taps;  // row-band vertical tables

@@ -1238,6 +1238,130 @@ hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, ui
 }
 
 // ------------------------------------------------------------------------------------------
+// Integer-ratio up-sampling (upsample.h, upsample_chain.inc): the fused resample + chain kernel and the plain resize
+// kernel for out = R x in.  Replaces resize_chain_kernel / resize_lds_kernel where the host's check holds; same
+// operations per sample, bit-identical output.
+// ------------------------------------------------------------------------------------------
+#include "upsample_chain.inc"
+
+// Rows per thread (one trip per workgroup, see upsample_chain.inc).  KC_UP_RU at build time overrides (tuning).
+#ifndef KC_UP_RU
+#define KC_UP_RU 4
+#endif
+static_assert(KC_UP_RU == KC_UPSAMPLE_ROWS, "kc_internal.hpp sizes the tiles for this many rows per thread");
+
+template <int K, int RU>
+struct UpInterpreted {  // the chain as the step interpreter runs it (first sightings, no hiprtc)
+    const ChainProgram &P;
+    __device__ __forceinline__ void operator()(const f4 (&in)[K][RU], f4 (&acc)[RU]) const { chain_run<K, RU, 0>(P, blockIdx.z, in, acc); }
+};
+
+template <int RU>
+struct UpStore {  // no chain: the resampled plane itself is the result
+    __device__ __forceinline__ void operator()(const f4 (&in)[1][RU], f4 (&acc)[RU]) const
+    {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) acc[u] = in[0][u];
+    }
+};
+
+#ifdef KC_UP_HARDWIRE  // tuning builds only: config #2's program ((A + U) * A - U) in place of the interpreter
+template <int K, int RU>
+struct UpHardwired {
+    __device__ __forceinline__ void operator()(const f4 (&in)[K][RU], f4 (&acc)[RU]) const
+    {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) acc[u] = (in[0][u] + in[K - 1][u]) * in[0][u] - in[K - 1][u];
+    }
+};
+#endif
+
+template <int K, int T, bool WIDE>
+__global__ __launch_bounds__(256) void upsample_chain_kernel(const ChainProgram P, const UpsampleArgs U)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef KC_UP_HARDWIRE
+    upsample_chain_tile<K, T, KC_UP_RU, WIDE>(P, U, lds, UpHardwired<K, KC_UP_RU>{});
+#else
+    upsample_chain_tile<K, T, KC_UP_RU, WIDE>(P, U, lds, UpInterpreted<K, KC_UP_RU>{ P });
+#endif
+}
+
+template <int T, bool WIDE>
+__global__ __launch_bounds__(256) void upsample_kernel(const UpsamplePlanes P, const UpsampleArgs U)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    upsample_chain_tile<1, T, KC_UP_RU, WIDE>(P, U, lds, UpStore<KC_UP_RU>{});
+}
+
+static bool upsample_args_ok(const UpsampleArgs &u, int batch)
+{
+    if (batch < 1 || batch > 4) return false;
+    if (u.tile_w % 4 != 0 || u.tile_w == 0 || u.tile_w > 1024 || 256u % (u.tile_w / 4) != 0) return false;
+    const uint32_t tile_h = upsample_tile_rows(u);
+    if (u.chunk == 0 || tile_h % u.chunk != 0 || u.V.ratio % u.chunk != 0 || u.H.ratio % 4 != 0) return false;
+    if (u.H.taps != u.V.taps || u.ncp % 4 != 0 || !u.H.qcls || !u.V.cls) return false;
+    if (u.H.n_out > 65535 || u.V.n_out > 65535) return false;  // up_div
+    if (u.ncp / 4 > 257 || ((u.H.ratio >> 2) + u.H.qb_lo + u.H.qb_hi) * u.H.taps > 256) return false;
+    return upsample_lds_bytes(u) <= 64 * 1024;
+}
+
+static dim3 upsample_grid(const UpsampleArgs &u, int batch)
+{
+    const uint32_t tile_h = upsample_tile_rows(u);
+    return dim3((u.H.n_out + u.tile_w - 1) / u.tile_w, (u.V.n_out + tile_h - 1) / tile_h, batch);
+}
+
+template <int K, bool WIDE>
+static hipError_t launch_upsample_chain_k(const ChainProgram &p, const UpsampleArgs &u, dim3 grid, size_t lds, hipStream_t s)
+{
+    switch (u.H.taps) {
+    case 1: upsample_chain_kernel<K, 1, WIDE><<<grid, 256, lds, s>>>(p, u); break;
+    case 3: upsample_chain_kernel<K, 3, WIDE><<<grid, 256, lds, s>>>(p, u); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_upsample_chain(const ChainProgram &p, int batch, const UpsampleArgs &u, hipStream_t s)
+{
+    if (u.H.n_out == 0 || u.V.n_out == 0) return hipSuccess;
+    if (!upsample_args_ok(u, batch) || p.n_ops < 1 || p.n_ops > KC_CHAIN_MAX_OPS) return hipErrorInvalidValue;
+    const size_t lds = upsample_lds_bytes(u);
+    const dim3 grid = upsample_grid(u, batch);
+    const bool wide = u.tile_w == 1024;
+    switch (p.n_in) {
+    case 1: return wide ? launch_upsample_chain_k<1, true>(p, u, grid, lds, s) : launch_upsample_chain_k<1, false>(p, u, grid, lds, s);
+    case 2: return wide ? launch_upsample_chain_k<2, true>(p, u, grid, lds, s) : launch_upsample_chain_k<2, false>(p, u, grid, lds, s);
+    case 3: return wide ? launch_upsample_chain_k<3, true>(p, u, grid, lds, s) : launch_upsample_chain_k<3, false>(p, u, grid, lds, s);
+    case 4: return wide ? launch_upsample_chain_k<4, true>(p, u, grid, lds, s) : launch_upsample_chain_k<4, false>(p, u, grid, lds, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <bool WIDE>
+static hipError_t launch_upsample_w(const UpsamplePlanes &p, const UpsampleArgs &u, dim3 grid, size_t lds, hipStream_t s)
+{
+    switch (u.H.taps) {
+    case 1: upsample_kernel<1, WIDE><<<grid, 256, lds, s>>>(p, u); break;
+    case 3: upsample_kernel<3, WIDE><<<grid, 256, lds, s>>>(p, u); break;
+    case 5: upsample_kernel<5, WIDE><<<grid, 256, lds, s>>>(p, u); break;
+    case 7: upsample_kernel<7, WIDE><<<grid, 256, lds, s>>>(p, u); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_upsample(const UpsamplePlanes &p, int batch, const UpsampleArgs &u, hipStream_t s)
+{
+    if (u.H.n_out == 0 || u.V.n_out == 0) return hipSuccess;
+    if (!upsample_args_ok(u, batch)) return hipErrorInvalidValue;
+    const size_t lds = upsample_lds_bytes(u);
+    const dim3 grid = upsample_grid(u, batch);
+    return u.tile_w == 1024 ? launch_upsample_w<true>(p, u, grid, lds, s) : launch_upsample_w<false>(p, u, grid, lds, s);
+}
+
+// ------------------------------------------------------------------------------------------
 // HeightToNormal: src/node/height_to_normal.rs:16-77 with the toroidal wrap of
 // src/node/process_shared.rs:31-65; nalgebra 0.29 normalize = v / sqrt((x*x + y*y) + z*z).
 // 4 B read + 12 B written per pixel (alpha is a constant plane).

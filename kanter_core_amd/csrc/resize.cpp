@@ -50,6 +50,62 @@ static float sinc(float t)
 
 static float k_lanczos3(float x) { return std::fabs(x) < 3.0f ? sinc(x) * sinc(x / 3.0f) : 0.0f; }
 
+// Does the table have the structure upsample.h describes?  Checked on the table itself, bit for bit: nothing about the
+// filter or the ratio is assumed beyond out = R x in.
+static void up_axis_build(uint32_t in_n, uint32_t out_n, TapsHost &t)
+{
+    t.up_ok = false;
+    t.up_rows.clear();
+    if (out_n % in_n != 0) return;
+    const uint32_t R = out_n / in_n, T = t.stride;
+    if (T % 2 == 0 || T > 7) return;
+    const int off = (int)(T - 1) / 2;
+    std::vector<float> rows((size_t)out_n * T, 0.0f);  // every window laid out from its unclamped start
+    for (uint32_t o = 0; o < out_n; ++o) {
+        const int u = (int)(o / R) - off;
+        const int lo = std::max(u, 0), hi = std::min(u + (int)T, (int)in_n);
+        if ((int)t.left[o] != lo || (int)(t.left[o] + t.count[o]) != hi) return;
+        for (uint32_t j = 0; j < t.count[o]; ++j) rows[(size_t)o * T + (uint32_t)(lo - u) + j] = t.w[(size_t)o * t.stride + j];
+    }
+    // the phases' rows are those of a period in the middle; whatever differs from them must sit at either end
+    const uint32_t ref = (in_n / 2) * R;
+    auto same = [&](uint32_t o) { return std::memcmp(&rows[(size_t)o * T], &rows[(size_t)(ref + o % R) * T], T * sizeof(float)) == 0; };
+    uint32_t b_lo = 0, hi_start = out_n;
+    for (uint32_t o = 0; o < ref; ++o)
+        if (!same(o)) b_lo = o + 1;
+    for (uint32_t o = out_n; o-- > ref + R;)
+        if (!same(o)) hi_start = o;
+    const uint32_t b_hi = out_n - hi_start;
+    if ((size_t)(R + b_lo + b_hi) * T > 2048 || R > 65535 || out_n > 65535) return;  // the rows live in LDS; up_div
+    t.up = UpAxis{};
+    t.up.n_in = in_n;
+    t.up.n_out = out_n;
+    t.up.ratio = R;
+    t.up.magic = R > 1 ? (uint32_t)((0x100000000ull + R - 1) / R) : 0u;
+    t.up.taps = T;
+    t.up.off = off;
+    t.up.b_lo = b_lo;
+    t.up.b_hi = b_hi;
+    t.up_rows.assign(rows.begin() + (size_t)ref * T, rows.begin() + (size_t)(ref + R) * T);
+    t.up_rows.insert(t.up_rows.end(), rows.begin(), rows.begin() + (size_t)b_lo * T);
+    t.up_rows.insert(t.up_rows.end(), rows.begin() + (size_t)hi_start * T, rows.end());
+    // quad classes (R % 4 == 0: the four columns of a quad share their window): tap-major blocks of 4 weights
+    t.up_qrows.clear();
+    if (R % 4 == 0) {
+        const uint32_t nqx = out_n / 4, qb_lo = (b_lo + 3) / 4, qb_hi = (b_hi + 3) / 4;
+        auto block = [&](uint32_t o0) {
+            for (uint32_t j = 0; j < T; ++j)
+                for (uint32_t e = 0; e < 4; ++e) t.up_qrows.push_back(rows[(size_t)(o0 + e) * T + j]);
+        };
+        for (uint32_t c = 0; c < R / 4; ++c) block(ref + 4 * c);
+        for (uint32_t q = 0; q < qb_lo; ++q) block(4 * q);
+        for (uint32_t q = nqx - qb_hi; q < nqx; ++q) block(4 * q);
+        t.up.qb_lo = qb_lo;
+        t.up.qb_hi = qb_hi;
+    }
+    t.up_ok = true;
+}
+
 int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
 {
     float (*kern)(float) = nullptr;
@@ -125,6 +181,7 @@ int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
             }
         }
     }
+    up_axis_build(in_n, out_n, t);
     return KC_OK;
 }
 
@@ -135,12 +192,19 @@ static int taps_upload(TapsEntry &e)
     const size_t nl = e.host.left.size() * sizeof(uint32_t);
     const size_t nw = e.host.w.size() * sizeof(float);
     const size_t nl_pad = (nl + 255) / 256 * 256;
-    e.dev_bytes = 2 * nl_pad + (nw + 32 + 255) / 256 * 256;  // + 32: register-tap loads past the last row
+    const size_t nw_pad = (nw + 32 + 255) / 256 * 256;  // + 32: register-tap loads past the last row
+    const size_t nu = e.host.up_ok ? e.host.up_rows.size() * sizeof(float) : 0;
+    const size_t nu_pad = (nu + 255) / 256 * 256;
+    const size_t nuq = e.host.up_ok ? e.host.up_qrows.size() * sizeof(float) : 0;
+    e.dev_bytes = 2 * nl_pad + nw_pad + nu_pad + (nuq + 255) / 256 * 256;
     KC_HIP(hipMalloc(&e.dev_block, e.dev_bytes));
     char *base = (char *)e.dev_block;
     hipError_t err = hipMemcpyAsync(base, e.host.left.data(), nl, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess) err = hipMemcpyAsync(base + nl_pad, e.host.count.data(), nl, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess) err = hipMemcpyAsync(base + 2 * nl_pad, e.host.w.data(), nw, hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess && nu) err = hipMemcpyAsync(base + 2 * nl_pad + nw_pad, e.host.up_rows.data(), nu, hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess && nuq)
+        err = hipMemcpyAsync(base + 2 * nl_pad + nw_pad + nu_pad, e.host.up_qrows.data(), nuq, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
     if (err != hipSuccess) {
         (void)hipFree(e.dev_block);
@@ -151,6 +215,8 @@ static int taps_upload(TapsEntry &e)
     e.dev.count = (const uint32_t *)(base + nl_pad);
     e.dev.w = (const float *)(base + 2 * nl_pad);
     e.dev.stride = e.host.stride;
+    if (nu) e.host.up.cls = (const float *)(base + 2 * nl_pad + nw_pad);
+    if (nuq) e.host.up.qcls = (const float *)(base + 2 * nl_pad + nw_pad + nu_pad);
     return KC_OK;
 }
 
@@ -356,6 +422,46 @@ static TileChoice choose_tile(const TapsEntry &tv, const TapsEntry &th, kc_size 
     return t;
 }
 
+// Integer-ratio up-sampling on both axes (upsample.h): tile and LDS pitch for upsample_chain_tile, or false.
+static bool up_plan(const TapsEntry &tv, const TapsEntry &th, UpsampleArgs &u)
+{
+    Context &c = ctx();
+    if (c.resize_mode >= 3 || !tv.host.up_ok || !th.host.up_ok) return false;
+    u.H = th.host.up;
+    u.V = tv.host.up;
+    if (u.H.taps != u.V.taps || u.H.ratio % 4 != 0 || !u.H.qcls || !u.V.cls) return false;
+    const uint32_t dw = u.H.n_out, R = u.H.ratio, T = u.H.taps;
+    // widest tile that wastes the fewest threads on columns past the image (narrower tiles are taller: a thread always
+    // owns 4 columns x KC_UPSAMPLE_ROWS rows)
+    uint32_t best = 0, best_pad = 0;
+    for (uint32_t tw : { 1024u, 512u, 256u, 128u, 64u, 32u, 16u }) {
+        const uint32_t pad = (dw + tw - 1) / tw * tw;
+        if (!best || pad < best_pad) {
+            best = tw;
+            best_pad = pad;
+        }
+    }
+    if (c.resize_tile_w > 0 && c.resize_tile_w % 4 == 0 && c.resize_tile_w <= 1024 && 256 % (c.resize_tile_w / 4) == 0)
+        best = (uint32_t)c.resize_tile_w;  // KC_RESIZE_TILE_W: tuning
+    u.tile_w = best;
+    uint32_t quads = 1;  // the widest window any tile needs, in source quads, exactly as the kernel lays it out
+    for (uint32_t x0 = 0; x0 < dw; x0 += u.tile_w) {
+        const uint32_t x1 = std::min(dw, x0 + u.tile_w);
+        const int cq0 = ((int)(x0 / R) - u.H.off) >> 2;
+        const int last = (int)((x1 - 1) / R) - u.H.off + (int)(T - 1);
+        quads = std::max(quads, (uint32_t)((last >> 2) - cq0) + 1u);
+    }
+    u.ncp = 4u * (quads | 1u);  // an odd quad count staggers consecutive rows over the LDS banks
+    if (quads > 256 || ((R >> 2) + u.H.qb_lo + u.H.qb_hi) * T > 256) return false;  // one vertical item / one class quad per thread
+    u.chunk = 1;  // the most rows that share a window and divide the tile's rows (a multiple of KC_UPSAMPLE_ROWS)
+    for (uint32_t d : { 8u, 4u, 2u })
+        if (u.V.ratio % d == 0 && KC_UPSAMPLE_ROWS % d == 0) {
+            u.chunk = d;
+            break;
+        }
+    return upsample_lds_bytes(u) <= 64 * 1024;
+}
+
 // Runs the resample srcs[i] -> dsts[i] (all resident; equal source sizes, equal target sizes) with the given tap
 // tables: one launch for the whole batch in the tiled form, two per plane in the two-pass form.
 static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, TapsEntry *tv, TapsEntry *th)
@@ -365,6 +471,22 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
     const kc_size size{ dsts[0]->w, dsts[0]->h };
     // Tiled single pass when a tile's vertical-pass intermediate and tap tables fit in LDS; very wide
     // windows fall back to two passes through an HBM intermediate (KC_RESIZE_MODE=3 forces them).
+    UpsampleArgs ua{};
+    if (up_plan(*tv, *th, ua)) {
+        UpsamplePlanes up{};
+        for (int i = 0; i < n; ++i) {
+            up.samp_src[i] = srcs[i]->dptr;
+            up.samp_pitch[i] = (uint32_t)(srcs[i]->pitch / 4);
+            up.out[i] = dsts[i]->dptr;
+            up.out_pitch[i] = (uint32_t)(dsts[i]->pitch / 16);
+        }
+        hipError_t e = launch_upsample(up, n, ua, c.stream);
+        if (e != hipSuccess) return hip_fail(e, "launch_upsample");
+        c.launches++;
+        c.counters["upsample_launches"]++;
+        c.alg_bytes += (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height);
+        return KC_OK;
+    }
     if (c.resize_mode != 3) {
         const TileChoice t = choose_tile(*tv, *th, size);
         if (t.ok) {
@@ -506,11 +628,20 @@ int chain_resize_launch(const ChainProgram &P, int batch, int mode, kc_plane *co
     TapsEntry *tv = nullptr, *th = nullptr;
     KC_TRY(get_taps(s0->rz_src->h, size.height, s0->rz_filter, &tv));
     KC_TRY(get_taps(s0->rz_src->w, size.width, s0->rz_filter, &th));
+    UpsampleArgs ua{};
+    if (up_plan(*tv, *th, ua) && ua.H.taps <= 3) {
+        hipError_t e = launch_upsample_chain(P, batch, ua, c.stream);
+        if (e != hipSuccess) return hip_fail(e, "launch_upsample_chain");
+        c.counters["upsample_chain_launches"]++;
+        *launched = true;
+        return KC_OK;
+    }
     if (th->host.stride > 4) return KC_OK;
     const TileChoice t = choose_tile(*tv, *th, size);
     if (!t.ok) return KC_OK;
     hipError_t e = launch_resize_chain(P, batch, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, c.stream);
     if (e != hipSuccess) return hip_fail(e, "launch_resize_chain");
+    c.counters["resize_chain_launches"]++;
     *launched = true;
     return KC_OK;
 }
