@@ -369,7 +369,12 @@ def main():
     # fusion pattern is decided at run time (fanin: the add tree continues some of the branch chains) it is the figure.
     formula_bytes = alg_bytes
     alg_bytes = counted[0]
-    if kc.specialize_stats()["specialized_launches"] and "chain_kernel<" in kernel:
+    if args.workload == "resize_blend" and kc.stats_counter("upsample_chain_launches"):
+        # the integer-ratio up-sampling form (csrc/upsample_chain.inc) replaced resize_chain_kernel for this launch
+        kernel = ("kc_upchain_<hash> (upsample_chain_tile<2,3,4,wide> with the chain program compiled to straight-line code at run "
+                  "time, csrc/specialize.cpp; upsample_chain_kernel<2,3,true> = the same tile code driven by the step interpreter, "
+                  "first sightings only)") if kc.specialize_stats()["specialized_launches"] else "upsample_chain_kernel<2,3,true>"
+    elif kc.specialize_stats()["specialized_launches"] and "chain_kernel<" in kernel:
         kernel = "kc_chain_<hash> (the chain program compiled to straight-line code at run time, csrc/specialize.cpp; " + kernel + " = the interpreter, first sightings only)"
     main_step_us = step_spread(step, max(20, min(args.steps, 100)))
     total_px = node_px

@@ -133,6 +133,11 @@ KC_API int kc_get_fusion(void);
  * (src/shared.rs:159-199 has one code path). */
 KC_API int kc_set_resize_mode(int mode);
 KC_API int kc_get_resize_mode(void);
+/* Cache policy (a throughput knob; results are identical): 1 (default, env KC_CACHE_POLICY) = a launch that streams more
+ * than the 256 MB Infinity Cache can hold reads its full-size inputs with the nontemporal hint and keeps its result
+ * cacheable while that fits; 0 = plain loads and stores everywhere. */
+KC_API int kc_set_cache_policy(int mode);
+KC_API int kc_get_cache_policy(void);
 /* Diagnostics (host only, works without a device): the structure the integer-ratio up-sampling kernels rely on,
  * for one axis of image::imageops::resize (src/shared.rs:159-199) from in_n to out_n samples with `filter`.
  * *eligible = 0: the tap table does not have it (not a whole ratio, an even window ...) and the general kernels run.
@@ -170,6 +175,11 @@ KC_API int kc_specialize_stats(uint64_t *kernels_compiled, uint64_t *compiles_fa
  * without a device.  The generated source is copied to `source` (NUL-terminated, truncated to `cap`) when given. */
 KC_API int kc_specialize_compile_check(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, int flat,
                                        char *source, size_t cap);
+/* The same for a program that runs inside the integer-ratio up-sampling kernel (the resampled operand is input slot
+ * n_in - 1; `taps` = 1 or 3 per axis, `wide` = the 1024-column tile form): src/shared.rs:159-199 feeding
+ * src/node/mix.rs:136-192 in one launch. */
+KC_API int kc_specialize_compile_check_upsample(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, uint32_t taps,
+                                                int wide, char *source, size_t cap);
 
 /* ========================================================================================== *
  * Planes -- replaces Buffer / TransientBufferContainer (src/slot_image.rs:12,

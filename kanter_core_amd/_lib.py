@@ -56,6 +56,8 @@ SIGNATURES = {
     "kc_set_fusion": (C.c_int, [C.c_int]),
     "kc_set_resize_mode": (C.c_int, [C.c_int]),
     "kc_get_resize_mode": (C.c_int, []),
+    "kc_set_cache_policy": (C.c_int, [C.c_int]),
+    "kc_get_cache_policy": (C.c_int, []),
     "kc_stats_counter": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64)]),
     "kc_resize_upsample_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_float), C.c_size_t]),
@@ -66,6 +68,8 @@ SIGNATURES = {
     "kc_specialize_wait": (C.c_int, []),
     "kc_specialize_stats": (C.c_int, [C.POINTER(C.c_uint64)] * 4),
     "kc_specialize_compile_check": (C.c_int, [c_u32p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "kc_specialize_compile_check_upsample": (C.c_int, [c_u32p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_char_p,
+                                                       C.c_size_t]),
     "kc_stats_algorithmic_bytes": (C.c_int, [C.POINTER(C.c_uint64)]),
     "kc_pool_trim": (C.c_int, []),
     "kc_live_graph_partition": (C.c_int, [c_vp, C.c_uint32, C.c_int, C.c_int, C.POINTER(c_vp)]),

@@ -96,6 +96,15 @@ def get_resize_mode():
     return _lib.load().kc_get_resize_mode()
 
 
+def set_cache_policy(mode):
+    """1: launches that stream more than the Infinity Cache holds mark those streams nontemporal; 0: plain accesses."""
+    _check(_lib.load().kc_set_cache_policy(int(mode)))
+
+
+def get_cache_policy():
+    return _lib.load().kc_get_cache_policy()
+
+
 def resize_upsample_plan(in_n, out_n, filter=None):
     """Host only: the structure the integer-ratio up-sampling kernels rely on for one axis (kc_resize_upsample_plan),
     as a dict {ratio, taps, off, b_lo, b_hi, rows: float32[ratio + b_lo + b_hi, taps]}, or None when the axis
@@ -142,6 +151,16 @@ def specialize_compile_check(words, n_in, start_src=0, flat=True):
     arr = (C.c_uint32 * len(words))(*words)
     buf = C.create_string_buffer(1 << 16)
     _check(_lib.load().kc_specialize_compile_check(arr, len(words), int(n_in), int(start_src), int(bool(flat)), buf, len(buf)))
+    return buf.value.decode()
+
+
+def specialize_compile_check_upsample(words, n_in, start_src=0, taps=3, wide=True):
+    """The same for a program that runs inside the integer-ratio up-sampling kernel (input n_in - 1 = the resampled
+    operand).  Returns the generated source."""
+    arr = (C.c_uint32 * len(words))(*words)
+    buf = C.create_string_buffer(1 << 17)
+    _check(_lib.load().kc_specialize_compile_check_upsample(arr, len(words), int(n_in), int(start_src), int(taps), int(bool(wide)),
+                                                            buf, len(buf)))
     return buf.value.decode()
 
 

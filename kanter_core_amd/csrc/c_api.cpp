@@ -77,6 +77,7 @@ try {
         if (v >= 1) c.max_blocks = v;
     }
     if (const char *rm = std::getenv("KC_RESIZE_MODE")) c.resize_mode = std::atoi(rm);
+    if (const char *cp = std::getenv("KC_CACHE_POLICY")) c.cache_policy = std::atoi(cp) != 0;
     if (const char *rt = std::getenv("KC_RESIZE_TILE_H")) c.resize_tile_h = std::atoi(rt);
     if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
     if (const char *cu = std::getenv("KC_CHAIN_UNROLL")) {
@@ -208,6 +209,17 @@ KC_CATCH
 
 int kc_get_resize_mode(void) { return ctx().resize_mode; }
 
+int kc_set_cache_policy(int mode)
+try {
+    KC_ARG(mode == 0 || mode == 1);
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    ctx().cache_policy = mode;
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_get_cache_policy(void) { return ctx().cache_policy; }
+
 int kc_resize_upsample_plan(uint32_t in_n, uint32_t out_n, int filter, int *eligible, int32_t info[5], float *rows, size_t cap)
 try {
     KC_ARG(eligible && info);
@@ -273,6 +285,35 @@ try {
     std::string log;
     int s = specialize_compile_only(P, &log);
     if (s != KC_OK) set_error("specialised chain kernel did not compile: " + log);
+    return s;
+}
+KC_CATCH
+
+int kc_specialize_compile_check_upsample(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, uint32_t taps, int wide,
+                                         char *source, size_t cap)
+try {
+    KC_ARG(words && n_ops >= 1 && n_ops <= (uint32_t)KC_CHAIN_MAX_OPS && n_in >= 1 && n_in <= (uint32_t)KC_CHAIN_MAX_IN);
+    KC_ARG(start_src >= -1 && start_src < (int)n_in && (taps == 1 || taps == 3));
+    ChainProgram P;
+    std::memset(&P, 0, sizeof P);
+    P.n_ops = n_ops;
+    P.n_in = n_in;
+    P.start_src = start_src;
+    for (uint32_t i = 0; i < n_ops; ++i) {
+        const uint32_t from = words[i] >> 8, code = words[i] & 0xffu;
+        KC_ARG(code <= CH_MUL_INV && from <= n_in && code != CH_DIV_L && code != CH_DIV_R && code != CH_POW_L && code != CH_POW_R);
+        ((i & 1u) ? P.step[0][i / 2].b : P.step[0][i / 2].a).word = words[i];
+    }
+    UpsampleArgs U{};
+    U.H.taps = U.V.taps = taps;
+    U.tile_w = wide ? 1024u : 256u;
+    if (source && cap) {
+        const std::string src = specialize_source(P, &U);
+        std::snprintf(source, cap, "%s", src.c_str());
+    }
+    std::string log;
+    int s = specialize_compile_only(P, &log, &U);
+    if (s != KC_OK) set_error("specialised up-sampling kernel did not compile: " + log);
     return s;
 }
 KC_CATCH

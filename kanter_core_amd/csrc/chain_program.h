@@ -44,6 +44,10 @@ struct ChainProgram {
     unsigned int row_units;  // vector units (float4 or float) per row; rows * row_units = work items
     unsigned int rows;
     int start_src;  // input index, or -1: start from start_c
+    // Cache policy of this launch, chosen by the host (runtime.cpp, cache_policy_mask): bit k = input plane k is read with
+    // the nontemporal hint (streamed once, not worth a place in the 256 MB Infinity Cache), bit 8 = the result is stored
+    // with it.  Honoured by the kernels compiled at run time and by the up-sampling kernels; a hint, never semantics.
+    unsigned int nt_mask;
     const float *in[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];
     unsigned int in_pitch[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];  // in vector units
     float *out[KC_CHAIN_MAX_BATCH];

@@ -92,6 +92,22 @@ inline size_t upsample_lds_bytes(const UpsampleArgs &u)
 {
     return ((size_t)upsample_tile_rows(u) * u.ncp + (size_t)((u.H.ratio >> 2) + u.H.qb_lo + u.H.qb_hi) * 4u * u.H.taps) * sizeof(float);
 }
+inline bool upsample_args_ok(const UpsampleArgs &u, int batch)
+{
+    if (batch < 1 || batch > 4) return false;
+    if (u.tile_w % 4 != 0 || u.tile_w == 0 || u.tile_w > 1024 || 256u % (u.tile_w / 4) != 0) return false;
+    const uint32_t tile_h = upsample_tile_rows(u);
+    if (u.chunk == 0 || tile_h % u.chunk != 0 || u.V.ratio % u.chunk != 0 || u.H.ratio % 4 != 0) return false;
+    if (u.H.taps != u.V.taps || u.ncp % 4 != 0 || !u.H.qcls || !u.V.cls) return false;
+    if (u.H.n_out > 65535 || u.V.n_out > 65535) return false;  // up_div
+    if (u.ncp / 4 > 257 || ((u.H.ratio >> 2) + u.H.qb_lo + u.H.qb_hi) * u.H.taps > 256) return false;
+    return upsample_lds_bytes(u) <= 64 * 1024;
+}
+inline dim3 upsample_grid(const UpsampleArgs &u, int batch)
+{
+    const uint32_t tile_h = upsample_tile_rows(u);
+    return dim3((u.H.n_out + u.tile_w - 1) / u.tile_w, (u.V.n_out + tile_h - 1) / tile_h, batch);
+}
 // The plane members of ChainProgram that the plain up-sampling kernel reads (K = 1: no resident inputs).
 struct UpsamplePlanes {
     const float *samp_src[4];
@@ -100,6 +116,7 @@ struct UpsamplePlanes {
     unsigned int out_pitch[4];  // float4 units
     const float *in[4][1];
     unsigned int in_pitch[4][1];
+    unsigned int nt_mask;  // bit 8: nontemporal stores (ChainProgram::nt_mask)
 };
 hipError_t launch_upsample_chain(const ChainProgram &p, int batch, const UpsampleArgs &u, hipStream_t s);
 hipError_t launch_upsample(const UpsamplePlanes &p, int batch, const UpsampleArgs &u, hipStream_t s);

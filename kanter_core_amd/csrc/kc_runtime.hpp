@@ -183,6 +183,7 @@ struct Context {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool fusion = true;
+    int cache_policy = 1;  // 1: launches whose streams exceed the Infinity Cache mark them nontemporal (cache_policy_mask); 0: plain loads / stores (KC_CACHE_POLICY, kc_set_cache_policy)
     int max_blocks = 4096;
     int chain_unroll = 0;  // float4 per thread per decode in the chain kernel; 0 = heuristic (KC_CHAIN_UNROLL)
     int resize_mode = 0;  // 0 auto (tiled single pass when a tile fits in LDS), 1 no resize_poly_kernel, 2 no resize_down_kernel either (A/B), 3 two passes through HBM only, 4 auto without the integer-ratio up-sampling kernels (KC_RESIZE_MODE, kc_set_resize_mode)
@@ -310,14 +311,18 @@ int chain_resize_launch(const ChainProgram &P, int batch, int mode, kc_plane *co
 
 // ---- run-time specialisation of the chain kernel (specialize.cpp) ----
 hipError_t launch_chain_specialized(const ChainProgram &P, int batch, hipStream_t s, bool *launched);
+// Which streams of a launch are marked nontemporal: `in_bytes` / `out_bytes` = what the launch reads from its n_resident
+// full-size input planes / writes, summed over its channels.  Returns the ChainProgram::nt_mask bits.
+uint32_t cache_policy_mask(uint64_t in_bytes, uint64_t out_bytes, uint32_t n_resident);
+hipError_t launch_upsample_chain_specialized(const ChainProgram &P, int batch, const UpsampleArgs &U, hipStream_t s, bool *launched);
 int specialize_set_mode(int mode, int after);  // 0 off, 1 background compile after `after` sightings, 2 compile at once
 int specialize_get_mode();
 void specialize_wait();
 void specialize_stats(uint64_t *compiled, uint64_t *failed, uint64_t *launches, uint64_t *pending);
 std::string specialize_last_log();
 void specialize_shutdown();
-std::string specialize_source(const ChainProgram &P);
-int specialize_compile_only(const ChainProgram &P, std::string *log);
+std::string specialize_source(const ChainProgram &P, const UpsampleArgs *U = nullptr);
+int specialize_compile_only(const ChainProgram &P, std::string *log, const UpsampleArgs *U = nullptr);
 
 // ---- png / json (png.cpp, json.cpp) ----
 int png_read(const std::string &path, std::vector<uint8_t> &px, uint32_t &w, uint32_t &h, int &channels);

@@ -1276,40 +1276,27 @@ struct UpHardwired {
 };
 #endif
 
+#ifdef KC_UP_SGPR
+#define KC_UP_ATTR __attribute__((amdgpu_num_sgpr(KC_UP_SGPR)))
+#else
+#define KC_UP_ATTR
+#endif
 template <int K, int T, bool WIDE>
-__global__ __launch_bounds__(256) void upsample_chain_kernel(const ChainProgram P, const UpsampleArgs U)
+__global__ __launch_bounds__(256) KC_UP_ATTR void upsample_chain_kernel(const ChainProgram P, const UpsampleArgs U)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef KC_UP_HARDWIRE
-    upsample_chain_tile<K, T, KC_UP_RU, WIDE>(P, U, lds, UpHardwired<K, KC_UP_RU>{});
+    upsample_chain_tile<K, T, KC_UP_RU, WIDE, 0u>(P, U, lds, UpHardwired<K, KC_UP_RU>{});
 #else
-    upsample_chain_tile<K, T, KC_UP_RU, WIDE>(P, U, lds, UpInterpreted<K, KC_UP_RU>{ P });
+    upsample_chain_tile<K, T, KC_UP_RU, WIDE, 0u>(P, U, lds, UpInterpreted<K, KC_UP_RU>{ P });
 #endif
 }
 
-template <int T, bool WIDE>
+template <int T, bool WIDE, bool NTS>  // NTS: the resampled planes are stored nontemporal (cache_policy_mask)
 __global__ __launch_bounds__(256) void upsample_kernel(const UpsamplePlanes P, const UpsampleArgs U)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    upsample_chain_tile<1, T, KC_UP_RU, WIDE>(P, U, lds, UpStore<KC_UP_RU>{});
-}
-
-static bool upsample_args_ok(const UpsampleArgs &u, int batch)
-{
-    if (batch < 1 || batch > 4) return false;
-    if (u.tile_w % 4 != 0 || u.tile_w == 0 || u.tile_w > 1024 || 256u % (u.tile_w / 4) != 0) return false;
-    const uint32_t tile_h = upsample_tile_rows(u);
-    if (u.chunk == 0 || tile_h % u.chunk != 0 || u.V.ratio % u.chunk != 0 || u.H.ratio % 4 != 0) return false;
-    if (u.H.taps != u.V.taps || u.ncp % 4 != 0 || !u.H.qcls || !u.V.cls) return false;
-    if (u.H.n_out > 65535 || u.V.n_out > 65535) return false;  // up_div
-    if (u.ncp / 4 > 257 || ((u.H.ratio >> 2) + u.H.qb_lo + u.H.qb_hi) * u.H.taps > 256) return false;
-    return upsample_lds_bytes(u) <= 64 * 1024;
-}
-
-static dim3 upsample_grid(const UpsampleArgs &u, int batch)
-{
-    const uint32_t tile_h = upsample_tile_rows(u);
-    return dim3((u.H.n_out + u.tile_w - 1) / u.tile_w, (u.V.n_out + tile_h - 1) / tile_h, batch);
+    upsample_chain_tile<1, T, KC_UP_RU, WIDE, (NTS ? 0x100u : 0u)>(P, U, lds, UpStore<KC_UP_RU>{});
 }
 
 template <int K, bool WIDE>
@@ -1339,14 +1326,14 @@ hipError_t launch_upsample_chain(const ChainProgram &p, int batch, const Upsampl
     }
 }
 
-template <bool WIDE>
+template <bool WIDE, bool NTS>
 static hipError_t launch_upsample_w(const UpsamplePlanes &p, const UpsampleArgs &u, dim3 grid, size_t lds, hipStream_t s)
 {
     switch (u.H.taps) {
-    case 1: upsample_kernel<1, WIDE><<<grid, 256, lds, s>>>(p, u); break;
-    case 3: upsample_kernel<3, WIDE><<<grid, 256, lds, s>>>(p, u); break;
-    case 5: upsample_kernel<5, WIDE><<<grid, 256, lds, s>>>(p, u); break;
-    case 7: upsample_kernel<7, WIDE><<<grid, 256, lds, s>>>(p, u); break;
+    case 1: upsample_kernel<1, WIDE, NTS><<<grid, 256, lds, s>>>(p, u); break;
+    case 3: upsample_kernel<3, WIDE, NTS><<<grid, 256, lds, s>>>(p, u); break;
+    case 5: upsample_kernel<5, WIDE, NTS><<<grid, 256, lds, s>>>(p, u); break;
+    case 7: upsample_kernel<7, WIDE, NTS><<<grid, 256, lds, s>>>(p, u); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1358,7 +1345,9 @@ hipError_t launch_upsample(const UpsamplePlanes &p, int batch, const UpsampleArg
     if (!upsample_args_ok(u, batch)) return hipErrorInvalidValue;
     const size_t lds = upsample_lds_bytes(u);
     const dim3 grid = upsample_grid(u, batch);
-    return u.tile_w == 1024 ? launch_upsample_w<true>(p, u, grid, lds, s) : launch_upsample_w<false>(p, u, grid, lds, s);
+    const bool nts = (p.nt_mask & 0x100u) != 0;
+    if (u.tile_w == 1024) return nts ? launch_upsample_w<true, true>(p, u, grid, lds, s) : launch_upsample_w<true, false>(p, u, grid, lds, s);
+    return nts ? launch_upsample_w<false, true>(p, u, grid, lds, s) : launch_upsample_w<false, false>(p, u, grid, lds, s);
 }
 
 // ------------------------------------------------------------------------------------------

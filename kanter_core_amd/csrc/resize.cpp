@@ -480,6 +480,7 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
             up.out[i] = dsts[i]->dptr;
             up.out_pitch[i] = (uint32_t)(dsts[i]->pitch / 16);
         }
+        up.nt_mask = cache_policy_mask(0, (uint64_t)n * 4 * size.width * size.height, 0);  // the small source stays cacheable
         hipError_t e = launch_upsample(up, n, ua, c.stream);
         if (e != hipSuccess) return hip_fail(e, "launch_upsample");
         c.launches++;
@@ -630,7 +631,10 @@ int chain_resize_launch(const ChainProgram &P, int batch, int mode, kc_plane *co
     KC_TRY(get_taps(s0->rz_src->w, size.width, s0->rz_filter, &th));
     UpsampleArgs ua{};
     if (up_plan(*tv, *th, ua) && ua.H.taps <= 3) {
-        hipError_t e = launch_upsample_chain(P, batch, ua, c.stream);
+        // the chain as straight-line code if that kernel has been compiled (specialize.cpp), otherwise the interpreter
+        bool spec = false;
+        hipError_t e = launch_upsample_chain_specialized(P, batch, ua, c.stream, &spec);
+        if (e == hipSuccess && !spec) e = launch_upsample_chain(P, batch, ua, c.stream);
         if (e != hipSuccess) return hip_fail(e, "launch_upsample_chain");
         c.counters["upsample_chain_launches"]++;
         *launched = true;

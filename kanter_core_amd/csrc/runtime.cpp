@@ -468,6 +468,25 @@ static int chain_prepare(kc_plane *p)
     return KC_OK;
 }
 
+// MI355X has a 256 MB memory-side Infinity Cache in front of HBM.  A launch that streams more than that through it
+// (the BASELINE graphs: 604 MB per evaluation at 4096^2) evicts everything before it is used again, and pays for the
+// allocations: the same 1-in-1-out stream runs at 5.9 TB/s with plain accesses and at 6.4-7.1 TB/s when the streams that
+// cannot stay are marked nontemporal (profiles/tilecopy.hip, r03_tilecopy3.txt).  Policy: a launch whose streams all fit
+// is left alone; otherwise its full-size inputs are read nontemporal, and its results are stored normally while they fit
+// by themselves -- the consumer of a result (the next node, an export, the next evaluation writing the same pool block)
+// then finds it on chip.
+uint32_t cache_policy_mask(uint64_t in_bytes, uint64_t out_bytes, uint32_t n_resident)
+{
+    if (!ctx().cache_policy) return 0;
+    static const long forced = std::getenv("KC_NT_FORCE") ? std::strtol(std::getenv("KC_NT_FORCE"), nullptr, 0) : -1;  // tuning: this mask for every launch
+    if (forced >= 0) return (uint32_t)forced & (((1u << n_resident) - 1u) | 0x100u);
+    const uint64_t budget = 208ull << 20;
+    if (in_bytes + out_bytes <= budget) return 0;
+    uint32_t mask = (1u << n_resident) - 1u;
+    if (out_bytes > budget) mask |= 0x100u;
+    return mask;
+}
+
 static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 {
     KC_PROF("chain_launch");
@@ -485,6 +504,11 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
         }
         P.out[b] = outs[b]->dptr;
         P.out_pitch[b] = (uint32_t)(outs[b]->pitch / 16);
+    }
+    {
+        const uint64_t px4 = 4ull * p0->w * p0->h;
+        const uint32_t resident = P.n_in - (bc.sampled[0] ? 1u : 0u);
+        P.nt_mask = cache_policy_mask(px4 * resident * batch, px4 * batch, resident);
     }
     bool launched = false;
     if (bc.sampled[0]) {

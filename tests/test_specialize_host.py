@@ -61,3 +61,32 @@ def test_mode_knob_round_trips():
         kc.set_specialize(old)
     kc.specialize_wait()
     assert kc.specialize_stats()["compiles_pending"] == 0
+
+
+# ---- the program inside the integer-ratio up-sampling kernel (upsample_chain.inc embedded as text) ----
+@pytest.mark.parametrize("wide", [True, False])
+@pytest.mark.parametrize("taps", [1, 3])
+def test_upsample_chain_form_compiles(taps, wide):
+    # config #2's program: ((A + U) * A) - U with A = input 0 and the resampled operand U = input 1
+    words = [word(ADD, 1), word(MUL, 0), word(SUB_L, 1)]
+    src = kc.specialize_compile_check_upsample(words, n_in=2, start_src=0, taps=taps, wide=wide)
+    body = src[src.index("struct UpProg"):]
+    assert "acc = acc + in[1][u];" in body and "acc = acc * in[0][u];" in body and "acc = acc - in[1][u];" in body
+    assert "upsample_chain_tile<2, %d, 4, %s, 0x0u>" % (taps, "true" if wide else "false") in body
+    assert "kc_upchain_" in body and "switch" not in body
+
+
+def test_upsample_chain_form_every_code_and_input_count():
+    codes = [ADD, SUB_L, SUB_R, MUL, ADD_INV, SUBL_INV, SUBR_INV, MUL_INV]
+    for n_in in (1, 2, 3, 4):
+        words = [word(c, i % n_in) for i, c in enumerate(codes)] + [word(c, -1) for c in (ADD, SUB_L, SUB_R, MUL)]
+        src = kc.specialize_compile_check_upsample(words, n_in=n_in, start_src=n_in - 1)
+        assert "f4 acc = in[%d][u];" % (n_in - 1) in src
+    src = kc.specialize_compile_check_upsample([word(MUL, 0)], n_in=1, start_src=-1)
+    assert "P.start_c[b]" in src
+
+
+def test_upsample_chain_form_refuses_divide_and_pow():
+    for code in (DIV_L, DIV_R, POW_L, POW_R):
+        with pytest.raises(kc.TexProError):
+            kc.specialize_compile_check_upsample([word(code, 0)], n_in=1)
