@@ -138,6 +138,11 @@ KC_API int kc_get_resize_mode(void);
  * cacheable while that fits; 0 = plain loads and stores everywhere. */
 KC_API int kc_set_cache_policy(int mode);
 KC_API int kc_get_cache_policy(void);
+/* Named A/B and test switches (results are identical whatever they say; unknown names are refused):
+ *   "chain1" 1 (default): a single Mix step runs its ahead-of-time straight-line kernel; 0: the step interpreter / the
+ *   run-time specialiser, as longer programs do. */
+KC_API int kc_set_option(const char *name, int value);
+KC_API int kc_get_option(const char *name, int *value);
 /* Diagnostics (host only, works without a device): the structure the integer-ratio up-sampling kernels rely on,
  * for one axis of image::imageops::resize (src/shared.rs:159-199) from in_n to out_n samples with `filter`.
  * *eligible = 0: the tap table does not have it (not a whole ratio, an even window ...) and the general kernels run.
@@ -154,7 +159,8 @@ KC_API int kc_stats(uint64_t *bytes_in_use, uint64_t *bytes_cached, uint64_t *ke
 KC_API int kc_stats_algorithmic_bytes(uint64_t *bytes);
 /* Named event counters since kc_init (tests and profiling: which kernel family a call went through).  Unknown names
  * read 0.  Names: "upsample_launches", "upsample_chain_launches" (the integer-ratio up-sampling kernels),
- * "resize_chain_launches" (the general fused resample + chain kernel). */
+ * "resize_chain_launches" (the general fused resample + chain kernel), "chain1_launches" (one-step programs through the
+ * ahead-of-time kernels). */
 KC_API int kc_stats_counter(const char *name, uint64_t *value);
 KC_API int kc_pool_trim(void);
 /* Run-time specialisation of the fused Mix-chain kernel.  A chain of N Mix nodes (src/node/mix.rs:136-192

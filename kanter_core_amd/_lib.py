@@ -57,6 +57,8 @@ SIGNATURES = {
     "kc_set_resize_mode": (C.c_int, [C.c_int]),
     "kc_get_resize_mode": (C.c_int, []),
     "kc_set_cache_policy": (C.c_int, [C.c_int]),
+    "kc_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "kc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "kc_get_cache_policy": (C.c_int, []),
     "kc_stats_counter": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64)]),
     "kc_resize_upsample_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32),

@@ -105,6 +105,17 @@ def get_cache_policy():
     return _lib.load().kc_get_cache_policy()
 
 
+def set_option(name, value):
+    """Named A/B and test switches (kc_set_option), e.g. "chain1"."""
+    _check(_lib.load().kc_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int()
+    _check(_lib.load().kc_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
 def resize_upsample_plan(in_n, out_n, filter=None):
     """Host only: the structure the integer-ratio up-sampling kernels rely on for one axis (kc_resize_upsample_plan),
     as a dict {ratio, taps, off, b_lo, b_hi, rows: float32[ratio + b_lo + b_hi, taps]}, or None when the axis

@@ -78,6 +78,7 @@ try {
     }
     if (const char *rm = std::getenv("KC_RESIZE_MODE")) c.resize_mode = std::atoi(rm);
     if (const char *cp = std::getenv("KC_CACHE_POLICY")) c.cache_policy = std::atoi(cp) != 0;
+    if (const char *c1 = std::getenv("KC_CHAIN1")) c.chain1 = std::atoi(c1) != 0;
     if (const char *rt = std::getenv("KC_RESIZE_TILE_H")) c.resize_tile_h = std::atoi(rt);
     if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
     if (const char *cu = std::getenv("KC_CHAIN_UNROLL")) {
@@ -219,6 +220,31 @@ try {
 KC_CATCH
 
 int kc_get_cache_policy(void) { return ctx().cache_policy; }
+
+int kc_set_option(const char *name, int value)
+try {
+    KC_ARG(name);
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    if (std::strcmp(name, "chain1") == 0) ctx().chain1 = value != 0;
+    else {
+        set_error(std::string("unknown option ") + name);
+        return KC_ERR_INVALID_ARG;
+    }
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_get_option(const char *name, int *value)
+try {
+    KC_ARG(name && value);
+    if (std::strcmp(name, "chain1") == 0) *value = ctx().chain1 ? 1 : 0;
+    else {
+        set_error(std::string("unknown option ") + name);
+        return KC_ERR_INVALID_ARG;
+    }
+    return KC_OK;
+}
+KC_CATCH
 
 int kc_resize_upsample_plan(uint32_t in_n, uint32_t out_n, int filter, int *eligible, int32_t info[5], float *rows, size_t cap)
 try {

@@ -37,6 +37,17 @@ struct Operand {
 // ---- kernel launchers (kernels.hip).  All enqueue on `s` and return hipGetLastError(). ----
 // mode: 0 = {+, -, *} only, 1 = + divide, 2 = + pow
 hipError_t launch_chain(const ChainProgram &p, int batch, int mode, int max_blocks, int unroll, hipStream_t s);
+// A one-step program for the ahead-of-time kernels of chain1.hip: result = op(start, operand), each a plane (pointer,
+// pitch in float4) or a broadcast constant (pointer null); c = the constant of the fused "c - ..." codes.
+struct Chain1Args {
+    const float *start[KC_CHAIN_MAX_BATCH], *operand[KC_CHAIN_MAX_BATCH];
+    float *out[KC_CHAIN_MAX_BATCH];
+    uint32_t start_pitch[KC_CHAIN_MAX_BATCH], operand_pitch[KC_CHAIN_MAX_BATCH], out_pitch[KC_CHAIN_MAX_BATCH];
+    float start_c[KC_CHAIN_MAX_BATCH], operand_c[KC_CHAIN_MAX_BATCH], c[KC_CHAIN_MAX_BATCH];
+    uint32_t row_units, rows;
+};
+// nt: bit 0 = the start plane, bit 1 = the operand plane, bit 2 = the result carry the nontemporal hint
+hipError_t launch_chain1(const Chain1Args &a, int batch, int code, unsigned nt, hipStream_t s);
 inline uint32_t chain_op_word(uint8_t code, int src) { return (uint32_t)code | ((uint32_t)(src + 1) << 8); }
 hipError_t launch_fill(float *dst, uint32_t pitch_floats, uint32_t w, uint32_t h, float v, hipStream_t s);
 hipError_t launch_resize_vertical(const float *src, uint32_t spitch, uint32_t sw, float *tmp, uint32_t tpitch,
@@ -120,11 +131,12 @@ struct UpsamplePlanes {
 };
 hipError_t launch_upsample_chain(const ChainProgram &p, int batch, const UpsampleArgs &u, hipStream_t s);
 hipError_t launch_upsample(const UpsamplePlanes &p, int batch, const UpsampleArgs &u, hipStream_t s);
+// nt_mask: the launch's cache policy as cache_policy_mask() returns it (bits 0-7: inputs, bit 8: results)
 hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, uint32_t full_h, int band,
-                                   float *nx, float *ny, float *nz, uint32_t opitch, hipStream_t s);
+                                   float *nx, float *ny, float *nz, uint32_t opitch, uint32_t nt_mask, hipStream_t s);
 hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,
-                        uint8_t *dst, hipStream_t s);
+                        uint8_t *dst, uint32_t nt_mask, hipStream_t s);
 hipError_t launch_from_u8(const uint8_t *src, int channels, uint32_t w, uint32_t h, float *const planes[4],
-                          uint32_t pitch, hipStream_t s);
+                          uint32_t pitch, uint32_t nt_mask, hipStream_t s);
 
 }  // namespace kc

@@ -26,46 +26,22 @@ static uint64_t grid_cap(uint64_t dflt)
     return v > 0 ? (uint64_t)v : dflt;
 }
 
-static __device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
+#include "chain_apply.inc"  // splat4, f4, kc_powf, apply1<CODE>: shared with chain1.hip
 
-// f32::powf (src/node/mix.rs:189), evaluated in f64 and rounded to f32 once (<= 1 ulp from any libm powf).
-// Positive finite base and finite exponent -- every pixel of ordinary image data -- take
-// pow_positive() (pow_positive.inc: 2^(b log2 a), ~75 f64 operations; against the f64 pow routine it
-// differs for about 1 pair in 10^8, by one ulp: profiles/pow_check.hip).  Everything else (zero,
-// negative, infinite or NaN base, infinite or NaN exponent) goes to that routine, whose special-case
-// rules are powf's: pow(x, 0) = 1, pow(1, NaN) = 1, negative base with a non-integer exponent = NaN,
-// signed zeros and infinities by the exponent's parity ...
-#include "pow_positive.inc"
-
-static __device__ __noinline__ float pow_general(float a, float b) { return (float)pow((double)a, (double)b); }
-
-// `tab`: what pow_setup() returned (the LDS copy of kPowTab + coefficients); only the pow codes read it
-static __device__ __forceinline__ float kc_powf(float a, float b, const PowCtx *tab)
+// Loads / stores with the launch's cache policy (ChainProgram::nt_mask; runtime.cpp, cache_policy_mask) as a compile-time
+// property: NT = the stream does not fit the Infinity Cache and is marked nontemporal.
+template <bool NT, class V>
+static __device__ __forceinline__ V ld_policy(const V *p)
 {
-    if (a > 0.0f && a < __builtin_inff() && __builtin_fabsf(b) < __builtin_inff()) return pow_positive(a, b, *tab);
-    return pow_general(a, b);
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
-
-template <int CODE>
-static __device__ __forceinline__ float apply1(float acc, float x, float c = 0.0f, const PowCtx *tab = nullptr)
+template <bool NT, class V>
+static __device__ __forceinline__ void st_policy(V *p, V v)
 {
-    if constexpr (CODE == CH_ADD_INV) return c - (acc + x);
-    else if constexpr (CODE == CH_SUBL_INV) return c - (acc - x);
-    else if constexpr (CODE == CH_SUBR_INV) return c - (x - acc);
-    else if constexpr (CODE == CH_MUL_INV) return c - (acc * x);
-    else if constexpr (CODE == CH_ADD) return acc + x;
-    else if constexpr (CODE == CH_SUB_L) return acc - x;
-    else if constexpr (CODE == CH_SUB_R) return x - acc;
-    else if constexpr (CODE == CH_MUL) return acc * x;
-    else if constexpr (CODE == CH_DIV_L) return acc / x;
-    else if constexpr (CODE == CH_DIV_R) return x / acc;
-    else if constexpr (CODE == CH_POW_L) return kc_powf(acc, x, tab);
-    else if constexpr (CODE == CH_POW_R) return kc_powf(x, acc, tab);
-    else if constexpr (CODE == CH_ADD_R) return x + acc;
-    else return x * acc;
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
 }
-
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 // One step on the U float4 a thread owns, written OUT OF PLACE (dst = op(src, x)): the decode
 // loop ping-pongs between two register sets, so no switch arm ever has to preserve or merge the
@@ -1543,7 +1519,7 @@ static __device__ __forceinline__ void h2n_quad(f4 px, f4 up, f4 left, float pdx
 // h + 1 rows, the band's rows preceded by the row above its first one (the caller's halo: the previous band's last
 // row, or the image's last row for the band that starts at row 0); `full_h` is the height of the whole image, which
 // is what the bitangent's 1 / height means (src/node/height_to_normal.rs:38).
-template <bool BAND>
+template <bool BAND, bool NT>  // NT: the three result planes do not fit the Infinity Cache (cache_policy_mask)
 __global__ __launch_bounds__(256) void height_to_normal_kernel(const float *__restrict__ hgt, uint32_t hpitch,
                                                                uint32_t w, uint32_t h, uint32_t full_h,
                                                                float *__restrict__ nx, float *__restrict__ ny,
@@ -1565,24 +1541,29 @@ __global__ __launch_bounds__(256) void height_to_normal_kernel(const float *__re
         f4 r, g, b;
         h2n_quad(cur, upv, f4{ lft, cur.x, cur.y, cur.z }, pdx, pdy, r, g, b);
         const size_t o = (size_t)y * opitch + 4 * q;
-        *reinterpret_cast<f4 *>(nx + o) = r;
-        *reinterpret_cast<f4 *>(ny + o) = g;
-        *reinterpret_cast<f4 *>(nz + o) = b;
+        st_policy<NT>(reinterpret_cast<f4 *>(nx + o), r);
+        st_policy<NT>(reinterpret_cast<f4 *>(ny + o), g);
+        st_policy<NT>(reinterpret_cast<f4 *>(nz + o), b);
     }
 }
 
 // h = rows to produce; band != 0: `hgt` has h + 1 rows (halo row first) and full_h is the whole image's height.
 hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w, uint32_t h, uint32_t full_h, int band,
-                                   float *nx, float *ny, float *nz, uint32_t opitch, hipStream_t s)
+                                   float *nx, float *ny, float *nz, uint32_t opitch, uint32_t nt_mask, hipStream_t s)
 {
+    const bool nts = (nt_mask & 0x100u) != 0;  // the height plane is re-read by neighbouring rows: never marked
     const uint64_t total = (uint64_t)((w + 3) / 4) * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > grid_cap(1u << 30)) blocks = grid_cap(1u << 30);
-    if (band)
-        height_to_normal_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch);
+    if (band && nts)
+        height_to_normal_kernel<true, true><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch);
+    else if (band)
+        height_to_normal_kernel<true, false><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch);
+    else if (nts)
+        height_to_normal_kernel<false, true><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, h, nx, ny, nz, opitch);
     else
-        height_to_normal_kernel<false><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, h, nx, ny, nz, opitch);
+        height_to_normal_kernel<false, false><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, h, nx, ny, nz, opitch);
     return hipGetLastError();
 }
 
@@ -1622,13 +1603,15 @@ static __device__ __forceinline__ uint32_t quant_u8_srgb(float v, const uint32_t
     return q;
 }
 
+template <bool NT>
 static __device__ __forceinline__ float4 load_operand4(const Operand &o, uint32_t row, uint32_t q)
 {
     if (o.ptr == nullptr) return splat4(o.c);
-    return *reinterpret_cast<const float4 *>(o.ptr + (size_t)row * o.pitch + 4 * q);
+    const f4 v = ld_policy<NT>(reinterpret_cast<const f4 *>(o.ptr + (size_t)row * o.pitch + 4 * q));
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 
-template <bool SRGB>
+template <bool SRGB, bool NT>  // NT: the planes are read once and do not fit the Infinity Cache (cache_policy_mask)
 __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operand b, Operand a, int gray, uint32_t w,
                                                     uint32_t h, uint8_t *__restrict__ dst)
 {
@@ -1643,7 +1626,7 @@ __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operan
     for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
         const uint32_t y = idx / row_units;
         const uint32_t q = idx - y * row_units;
-        const float4 vr = load_operand4(r, y, q);
+        const float4 vr = load_operand4<NT>(r, y, q);
         float rr[4] = { vr.x, vr.y, vr.z, vr.w };
         uint32_t px[4];
         if (gray) {
@@ -1653,9 +1636,9 @@ __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operan
                 px[e] = v | (v << 8) | (v << 16) | (255u << 24);
             }
         } else {
-            const float4 vg = load_operand4(g, y, q);
-            const float4 vb = load_operand4(b, y, q);
-            const float4 va = load_operand4(a, y, q);
+            const float4 vg = load_operand4<NT>(g, y, q);
+            const float4 vb = load_operand4<NT>(b, y, q);
+            const float4 va = load_operand4<NT>(a, y, q);
             float gg[4] = { vg.x, vg.y, vg.z, vg.w };
             float bb[4] = { vb.x, vb.y, vb.z, vb.w };
             float aa[4] = { va.x, va.y, va.z, va.w };
@@ -1680,21 +1663,27 @@ __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operan
 }
 
 hipError_t launch_to_u8(Operand r, Operand g, Operand b, Operand a, int gray, int srgb, uint32_t w, uint32_t h,
-                        uint8_t *dst, hipStream_t s)
+                        uint8_t *dst, uint32_t nt_mask, hipStream_t s)
 {
+    const bool ntl = (nt_mask & 0xffu) != 0;
     const uint64_t total = (uint64_t)((w + 3) / 4) * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > grid_cap(1u << 30)) blocks = grid_cap(1u << 30);
-    if (srgb)
-        to_u8_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
+    if (srgb && ntl)
+        to_u8_kernel<true, true><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
+    else if (srgb)
+        to_u8_kernel<true, false><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
+    else if (ntl)
+        to_u8_kernel<false, true><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
     else
-        to_u8_kernel<false><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
+        to_u8_kernel<false, false><<<dim3((unsigned)blocks), 256, 0, s>>>(r, g, b, a, gray, w, h, dst);
     return hipGetLastError();
 }
 
 // deconstruct_image, src/shared.rs:16-56: interleaved u8 (1..4 channels) -> planar f32 / 255.;
 // channels the file lacks become constant planes on the host side (R,G,B = 0, A = 1).
+template <bool NT>  // NT: the planes written do not fit the Infinity Cache (cache_policy_mask)
 __global__ __launch_bounds__(256) void from_u8_kernel(const uint8_t *__restrict__ src, int channels, uint32_t w,
                                                       uint32_t h, float *p0, float *p1, float *p2, float *p3,
                                                       uint32_t pitch)
@@ -1706,10 +1695,10 @@ __global__ __launch_bounds__(256) void from_u8_kernel(const uint8_t *__restrict_
         const uint32_t x = idx - y * w;
         if (channels == 4) {
             const uint32_t v = reinterpret_cast<const uint32_t *>(src)[idx];
-            p0[(size_t)y * pitch + x] = (float)(v & 255u) / 255.0f;
-            p1[(size_t)y * pitch + x] = (float)((v >> 8) & 255u) / 255.0f;
-            p2[(size_t)y * pitch + x] = (float)((v >> 16) & 255u) / 255.0f;
-            p3[(size_t)y * pitch + x] = (float)(v >> 24) / 255.0f;
+            st_policy<NT>(&p0[(size_t)y * pitch + x], (float)(v & 255u) / 255.0f);
+            st_policy<NT>(&p1[(size_t)y * pitch + x], (float)((v >> 8) & 255u) / 255.0f);
+            st_policy<NT>(&p2[(size_t)y * pitch + x], (float)((v >> 16) & 255u) / 255.0f);
+            st_policy<NT>(&p3[(size_t)y * pitch + x], (float)(v >> 24) / 255.0f);
         } else {
             for (int c = 0; c < channels; ++c)
                 planes[c][(size_t)y * pitch + x] = (float)src[(size_t)idx * channels + c] / 255.0f;
@@ -1718,14 +1707,16 @@ __global__ __launch_bounds__(256) void from_u8_kernel(const uint8_t *__restrict_
 }
 
 hipError_t launch_from_u8(const uint8_t *src, int channels, uint32_t w, uint32_t h, float *const planes[4],
-                          uint32_t pitch, hipStream_t s)
+                          uint32_t pitch, uint32_t nt_mask, hipStream_t s)
 {
     const uint64_t total = (uint64_t)w * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > grid_cap(1u << 30)) blocks = grid_cap(1u << 30);
-    from_u8_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(src, channels, w, h, planes[0], planes[1], planes[2],
-                                                          planes[3], pitch);
+    if (nt_mask & 0x100u)
+        from_u8_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(src, channels, w, h, planes[0], planes[1], planes[2], planes[3], pitch);
+    else
+        from_u8_kernel<false><<<dim3((unsigned)blocks), 256, 0, s>>>(src, channels, w, h, planes[0], planes[1], planes[2], planes[3], pitch);
     return hipGetLastError();
 }
 

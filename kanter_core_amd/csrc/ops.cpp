@@ -113,7 +113,8 @@ int image_from_u8(const uint8_t *host, uint32_t w, uint32_t h, int channels, kc_
             e = hipMemcpyAsync(staging, host, nbytes, hipMemcpyHostToDevice, c.stream);
         }
         if (e == hipSuccess)
-            e = launch_from_u8((const uint8_t *)staging, channels, w, h, dp, (uint32_t)(p[0]->pitch / 4), c.stream);
+            e = launch_from_u8((const uint8_t *)staging, channels, w, h, dp, (uint32_t)(p[0]->pitch / 4),
+                               cache_policy_mask((uint64_t)w * h * channels, (uint64_t)w * h * 4 * channels, 1), c.stream);
         if (e == hipSuccess && !slot) e = hipStreamSynchronize(c.stream);
         if (e != hipSuccess) s = hip_fail(e, "image_from_u8");
         else {
@@ -141,8 +142,10 @@ int image_to_u8(kc_image *img, bool srgb, uint8_t *host)
     KC_TRY(pool_alloc(block, &staging));
     Operand o[4];
     for (int i = 0; i < 4; ++i) o[i] = plane_operand(img->planes[img->is_rgba() ? i : 0]);
-    hipError_t e = launch_to_u8(o[0], o[1], o[2], o[3], img->is_rgba() ? 0 : 1, srgb ? 1 : 0, w, h,
-                                (uint8_t *)staging, c.stream);
+    uint32_t n_res = 0;
+    for (int i = 0; i < (img->is_rgba() ? 4 : 1); ++i) n_res += o[i].ptr != nullptr;
+    hipError_t e = launch_to_u8(o[0], o[1], o[2], o[3], img->is_rgba() ? 0 : 1, srgb ? 1 : 0, w, h, (uint8_t *)staging,
+                                cache_policy_mask((uint64_t)w * h * 4 * n_res, nbytes, n_res ? n_res : 1), c.stream);
     if (e == hipSuccess) {
         c.launches++;
         int resident = 0;
@@ -354,7 +357,8 @@ static int height_to_normal_impl(kc_image *in, uint32_t full_h, kc_image **out)
     for (int i = 0; i < 3 && s == KC_OK; ++i) s = plane_new_mem(w, h, &p[i]);
     if (s == KC_OK) {
         hipError_t e = launch_height_to_normal(src->dptr, (uint32_t)(src->pitch / 4), w, h, band ? full_h : h, band ? 1 : 0,
-                                               p[0]->dptr, p[1]->dptr, p[2]->dptr, (uint32_t)(p[0]->pitch / 4), c.stream);
+                                               p[0]->dptr, p[1]->dptr, p[2]->dptr, (uint32_t)(p[0]->pitch / 4),
+                                               cache_policy_mask((uint64_t)w * h * 4, (uint64_t)w * h * 12, 1), c.stream);
         if (e != hipSuccess) s = hip_fail(e, "launch_height_to_normal");
         else {
             c.launches++;

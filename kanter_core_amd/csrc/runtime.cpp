@@ -345,6 +345,7 @@ Operand plane_operand(const kc_plane *p)
 // ---- building the kernel program for one lazy plane -------------------------------------
 struct BuiltChain {
     ChainProgram prog;
+    uint32_t in_refs[KC_CHAIN_MAX_IN] = { 0, 0, 0, 0 };  // reference counts of channel 0's resident inputs when the program was built
     int mode = 0;  // 0 = {+,-,*}, 1 = + divide, 2 = + pow
     kc_plane *sampled[KC_CHAIN_MAX_BATCH] = { nullptr, nullptr, nullptr, nullptr };  // RESIZE operand per channel
 };
@@ -441,6 +442,7 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
     for (int k = 0; k < km; ++k) {
         P.in[b][k] = ins[k]->dptr;
         P.in_pitch[b][k] = (uint32_t)(ins[k]->pitch / 16);
+        if (b == 0) bc.in_refs[k] = (uint32_t)ins[k]->refs;
     }
     if (samp) {
         P.samp_src[b] = samp->rz_src->dptr;
@@ -475,6 +477,34 @@ static int chain_prepare(kc_plane *p)
 // is left alone; otherwise its full-size inputs are read nontemporal, and its results are stored normally while they fit
 // by themselves -- the consumer of a result (the next node, an export, the next evaluation writing the same pool block)
 // then finds it on chip.
+// The same for a chain launch, input by input.  A plane that nobody but the chain holds (refs == 1: an intermediate that
+// is freed as soon as the launch is enqueued) will never be read again; a plane somebody else holds as well -- a source
+// embedded in the graph, cached slot data, a caller's handle -- is read again by the next node or the next evaluation.  As
+// many of those as fit stay cacheable (most-referenced first), everything else is streamed; the result stays cacheable
+// only if it fits beside them.  Measured on config #1's traffic (profiles/tilecopy.hip add2, r03_tilecopy4.txt): plain
+// 102.9 us, everything streamed 92.6 us, one input kept 84.2 us -- and keeping the RESULT instead is 88.7 us when it goes
+// to the same block every time but 98.9 us when a graph still holds its previous result, which is the usual case.
+static uint32_t chain_cache_policy(const uint32_t *refs, uint32_t n, uint64_t stream_bytes, uint64_t out_bytes)
+{
+    if (!ctx().cache_policy) return 0;
+    static const long forced = std::getenv("KC_NT_FORCE") ? std::strtol(std::getenv("KC_NT_FORCE"), nullptr, 0) : -1;  // tuning: this mask for every launch
+    if (forced >= 0) return (uint32_t)forced & (((1u << n) - 1u) | 0x100u);
+    const uint64_t budget = 208ull << 20;
+    if (n * stream_bytes + out_bytes <= budget) return 0;
+    uint32_t mask = (1u << n) - 1u;
+    uint64_t used = 0;
+    for (;;) {
+        int best = -1;
+        for (uint32_t k = 0; k < n; ++k)
+            if ((mask >> k & 1u) && refs[k] >= 2 && (best < 0 || refs[k] > refs[best])) best = (int)k;
+        if (best < 0 || used + stream_bytes > budget) break;
+        used += stream_bytes;
+        mask &= ~(1u << best);
+    }
+    if (used + out_bytes > budget) mask |= 0x100u;
+    return mask;
+}
+
 uint32_t cache_policy_mask(uint64_t in_bytes, uint64_t out_bytes, uint32_t n_resident)
 {
     if (!ctx().cache_policy) return 0;
@@ -508,7 +538,7 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
     {
         const uint64_t px4 = 4ull * p0->w * p0->h;
         const uint32_t resident = P.n_in - (bc.sampled[0] ? 1u : 0u);
-        P.nt_mask = cache_policy_mask(px4 * resident * batch, px4 * batch, resident);
+        P.nt_mask = chain_cache_policy(bc.in_refs, resident, px4 * batch, px4 * batch);
     }
     bool launched = false;
     if (bc.sampled[0]) {
@@ -532,6 +562,36 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
     } else {
         P.rows = p0->h;
         P.row_units = row_units;
+    }
+    if (!launched && P.n_ops == 1 && c.chain1) {
+        // a single Mix step: its ahead-of-time straight-line kernel (chain1.hip)
+        Chain1Args a{};
+        const uint32_t w0 = P.step[0][0].a.word, from = w0 >> 8;
+        for (int b = 0; b < batch; ++b) {
+            if (P.start_src >= 0) {
+                a.start[b] = P.in[b][P.start_src];
+                a.start_pitch[b] = P.in_pitch[b][P.start_src];
+            }
+            a.start_c[b] = P.start_c[b];
+            if (from) {
+                a.operand[b] = P.in[b][from - 1];
+                a.operand_pitch[b] = P.in_pitch[b][from - 1];
+            }
+            a.operand_c[b] = a.c[b] = P.step[b][0].a.c;
+            a.out[b] = P.out[b];
+            a.out_pitch[b] = P.out_pitch[b];
+        }
+        a.rows = P.rows;
+        a.row_units = P.row_units;
+        const unsigned nt = (P.start_src >= 0 && (P.nt_mask >> P.start_src & 1u) ? 1u : 0u) | (from && (P.nt_mask >> (from - 1) & 1u) ? 2u : 0u) |
+                            (P.nt_mask & 0x100u ? 4u : 0u);
+        hipError_t e = launch_chain1(a, batch, (int)(w0 & 0xffu), nt, c.stream);
+        if (e != hipSuccess) {
+            for (auto *o : outs) plane_release(o);
+            return hip_fail(e, "launch_chain1");
+        }
+        c.counters["chain1_launches"]++;
+        launched = true;
     }
     if (!launched) {
         // a program-specialised straight-line kernel if one has been compiled (specialize.cpp) ...

@@ -13,7 +13,7 @@ echo "== $TAG"
 python3 - "$f" <<'PY'
 import csv, sys
 S = 4096 * 4096
-alg = {"to_u8_kernel<false>": 20, "to_u8_kernel<true>": 20, "from_u8_kernel": 20, "height_to_normal_kernel": 16, "fill_kernel": 4}
+alg = {"to_u8_kernel<false": 20, "to_u8_kernel<true": 20, "from_u8_kernel": 20, "height_to_normal_kernel": 16, "fill_kernel": 4}
 for r in sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: r["Name"]):
     n = r["Name"]
     if "kc::" not in n and "kc_chain_" not in n:

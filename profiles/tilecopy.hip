@@ -165,6 +165,17 @@ __global__ __launch_bounds__(256) void tile1_nt(Args p)
     }
 }
 
+// 2-in-1-out (a single Mix node, config #1): one float4 per lane, flat
+template <bool NTA, bool NTB, bool NTS>
+__global__ __launch_bounds__(256) void add2(const f4 *__restrict__ a, const f4 *__restrict__ b, f4 *__restrict__ o)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const f4 x = NTA ? __builtin_nontemporal_load(&a[i]) : a[i];
+    const f4 y = NTB ? __builtin_nontemporal_load(&b[i]) : b[i];
+    if (NTS) __builtin_nontemporal_store(x + y, &o[i]);
+    else o[i] = x + y;
+}
+
 int main()
 {
     const uint32_t W = 4096, H = 4096, w4 = W / 4;
@@ -210,6 +221,30 @@ int main()
     float *small;
     CK(hipMalloc((void **)&small, 4 << 20));
     CK(hipMemset(small, 0, 4 << 20));
+    {
+        // config #1's traffic: 201 MB + 201 MB read, 201 MB written, as three 3-plane buffers; the result goes to one
+        // buffer every launch ("same out") or to two in alternation ("2 outs": what a graph that still holds its previous
+        // result does)
+        const size_t big = 3 * bytes;
+        f4 *A, *B, *O[2];
+        CK(hipMalloc((void **)&A, big));
+        CK(hipMalloc((void **)&B, big));
+        CK(hipMalloc((void **)&O[0], big));
+        CK(hipMalloc((void **)&O[1], big));
+        CK(hipMemset(A, 0x3c, big));
+        CK(hipMemset(B, 0x3c, big));
+        const uint32_t nb = (uint32_t)(big / 16 / 256);
+        int flip = 0;
+#define ADD2(NAME, NA, NB, NS) \
+        run(NAME " same out", [&] { add2<NA, NB, NS><<<nb, 256>>>(A, B, O[0]); }); \
+        run(NAME " 2 outs", [&] { add2<NA, NB, NS><<<nb, 256>>>(A, B, O[flip++ & 1]); });
+        ADD2("add2 plain           ", false, false, false)
+        ADD2("add2 nt A,B          ", true, true, false)
+        ADD2("add2 nt A,B,store    ", true, true, true)
+        ADD2("add2 nt A,store      ", true, false, true)
+        ADD2("add2 nt store        ", false, false, true)
+        ADD2("add2 nt A            ", true, false, false)
+    }
     {
         // warm: the same 201 MB of inputs every launch (what a re-evaluated graph does); cold: three input sets in rotation
         // (603 MB of inputs against the 256 MB Infinity Cache)

@@ -26,13 +26,19 @@ def orc():
 
 
 def both_modes(kc, build):
-    """build() -> SlotImage (lazy); returns (interpreter planes, specialised planes, specialised launches)."""
-    kc.set_specialize(0)
-    a = build().planes()
-    kc.set_specialize(2)
-    n0 = kc.specialize_stats()
-    b = build().planes()
-    n1 = kc.specialize_stats()
+    """build() -> SlotImage (lazy); returns (interpreter planes, specialised planes, specialised launches).
+    One-step programs would run their ahead-of-time kernels (chain1.hip) before either: switched off here, see
+    test_single_mix_ahead_of_time_kernels for that route."""
+    kc.set_option("chain1", 0)
+    try:
+        kc.set_specialize(0)
+        a = build().planes()
+        kc.set_specialize(2)
+        n0 = kc.specialize_stats()
+        b = build().planes()
+        n1 = kc.specialize_stats()
+    finally:
+        kc.set_option("chain1", 1)
     assert n1["compiles_failed"] == n0["compiles_failed"], "a specialised kernel failed to compile"
     return a, b, n1["specialized_launches"] - n0["specialized_launches"]
 
@@ -81,6 +87,56 @@ def test_single_mix_every_op_and_operand_kind(kc, orc, op, side):
     assert_planes(spec, interp, what="%s %s" % (op, side))  # the two device paths agree bit for bit, Pow included
     want = orc.mix_plane(op, a if side != "scalar_left" else cplane, b if side != "scalar_right" else cplane)
     assert_planes(spec, [want], ulp=1 if op == "Pow" else 0, what="%s %s vs oracle" % (op, side))
+
+
+@pytest.mark.parametrize("shape", [(48, 200), (33, 130), (1, 7)])
+@pytest.mark.parametrize("op", ["Add", "Subtract", "Multiply", "Divide", "Pow"])
+@pytest.mark.parametrize("side", ["planes", "scalar_left", "scalar_right", "same_plane", "then_invert", "rgba"])
+def test_single_mix_ahead_of_time_kernels(kc, orc, op, side, shape):
+    """chain1.hip: a one-step program never reaches the interpreter; same bits as the interpreter, oracle-exact
+    (Pow: 1 ulp).  then_invert = Mix(op) followed by 1 - x, which the host folds into ONE record (CH_*_INV)."""
+    h, w = shape
+    a = with_edge_cases(splitmix_plane(SEED_A, 0, h, w), 0)
+    b = with_edge_cases(splitmix_plane(SEED_B, 0, h, w), 3)
+    c = np.float32(0.625)
+    cplane, ones = np.full((h, w), c, np.float32), np.ones((h, w), np.float32)
+    mt = kc.MixType.parse(op)
+
+    def build():
+        A, B = kc.SlotImage.from_planes([a]), kc.SlotImage.from_planes([b])
+        k = kc.resize_image(kc.value_process(float(c)), (w, h))
+        if side == "planes":
+            return kc.mix_process(A, B, mt)
+        if side == "scalar_left":
+            return kc.mix_process(k, B, mt)
+        if side == "scalar_right":
+            return kc.mix_process(A, k, mt)
+        if side == "same_plane":
+            return kc.mix_process(A, A, mt)
+        if side == "then_invert":
+            return kc.mix_process(kc.resize_image(kc.value_process(1.0), (w, h)), kc.mix_process(A, B, mt), kc.MixType.Subtract)
+        return kc.mix_process(kc.SlotImage.from_planes([a, b, a, ones]), kc.SlotImage.from_planes([b, b, a, ones]), mt)
+
+    # Divide / Pow followed by 1 - x stay two records: not a one-step program
+    expect = 0 if side == "then_invert" and op in ("Divide", "Pow") else 1
+    n0 = kc.stats_counter("chain1_launches")
+    got = build().planes()
+    assert kc.stats_counter("chain1_launches") - n0 == expect
+    kc.set_option("chain1", 0)
+    kc.set_specialize(0)
+    try:
+        interp = build().planes()
+        assert kc.stats_counter("chain1_launches") - n0 == expect
+    finally:
+        kc.set_option("chain1", 1)
+        kc.set_specialize(1)
+    assert_planes(got, interp, what="%s %s ahead-of-time vs interpreter" % (op, side))
+    m = lambda l, r: orc.mix_plane(op, l, r)
+    want = {"planes": lambda: [m(a, b)], "scalar_left": lambda: [m(cplane, b)], "scalar_right": lambda: [m(a, cplane)],
+            "same_plane": lambda: [m(a, a)], "then_invert": lambda: [orc.mix_plane("Subtract", ones, m(a, b))],
+            "rgba": lambda: [m(a, b), m(b, b), m(a, a), ones]}[side]()
+    if not (op == "Pow" and side == "then_invert"):  # 1 - x amplifies the one ulp Pow is allowed: interpreter-equal is the check there
+        assert_planes(got, want, ulp=1 if op == "Pow" else 0, what="%s %s vs oracle" % (op, side))
 
 
 def test_random_programs(kc, orc):
