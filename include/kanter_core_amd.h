@@ -369,6 +369,32 @@ KC_API int kc_partition_transfers(const kc_partition *p, kc_transfer *out, uint3
  * the result of a finished node (src/engine.rs:34-57): the receiving side of a transfer. */
 KC_API int kc_live_graph_import_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image *image);
 
+/* The exchange itself: RCCL send / recv of the slots a plan cuts, inside the library (librccl is bound at first use; a
+ * process that never calls these needs no RCCL).  One communicator per process:
+ *   kc_comm_unique_id   rank 0 fills `id` (KC_COMM_ID_BYTES); the host passes it to every rank by whatever channel it has
+ *                       (a file, MPI, torch.distributed's store ...);
+ *   kc_comm_init        collective over all ranks, after kc_init; a failure is a status (nothing is retried);
+ *   kc_live_graph_exchange  works through `transfers` in order -- every rank passes the same list, e.g. what
+ *                       kc_partition_transfers returns: the producer's rank evaluates the node (kernels enqueued, nobody
+ *                       waits), describes the slot in 64 bytes (size; constant planes travel as scalars, aliased planes once)
+ *                       and sends its planes behind an event of the compute stream; a consumer's rank allocates planes,
+ *                       receives into them on the communication stream and hands the slot over exactly as
+ *                       kc_live_graph_import_slot_data does, the compute stream waiting for the receive.  Consecutive entries
+ *                       of one slot are one multi-destination send.  An entry from a rank to itself is legal (the slot is
+ *                       replaced by the copy that came back): the one transfer a single-GPU machine can execute.
+ *   kc_live_graph_evaluate_partitioned  the whole evaluation: the exchange of `plan`, then `root` on the plan's home rank;
+ *                       `*out` (+1 ref) is the root's result there and NULL on the other ranks.
+ * The readiness rule that makes this correct is the reference's: a node needs nothing but its parents' slot data
+ * (src/engine.rs:213-275). */
+#define KC_COMM_ID_BYTES 256
+KC_API int kc_comm_unique_id(void *id);
+KC_API int kc_comm_init(int rank, int world_size, const void *id);
+KC_API int kc_comm_destroy(void);
+KC_API int kc_comm_info(int *rank, int *world_size);  /* 0, 0 without a communicator */
+KC_API int kc_comm_stats(uint64_t *planes_sent, uint64_t *planes_received, uint64_t *bytes_sent);
+KC_API int kc_live_graph_exchange(kc_live_graph *lg, const kc_transfer *transfers, uint32_t count);
+KC_API int kc_live_graph_evaluate_partitioned(kc_live_graph *lg, const kc_partition *plan, uint32_t root_node_id, kc_image **out);
+
 /* Row bands: rows [y0, y1) of a node's result without computing the rest -- the data-level way to put several GPUs on one
  * graph.  Every pixel goes through the same operations as in the whole-image evaluation (process_node, src/node/
  * node_type.rs:213-248), so the bands of all ranks, stacked, equal it bit for bit.  Pointwise nodes need the same rows

@@ -57,6 +57,13 @@ SIGNATURES = {
     "kc_set_resize_mode": (C.c_int, [C.c_int]),
     "kc_get_resize_mode": (C.c_int, []),
     "kc_set_cache_policy": (C.c_int, [C.c_int]),
+    "kc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "kc_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "kc_comm_destroy": (C.c_int, []),
+    "kc_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kc_comm_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "kc_live_graph_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "kc_live_graph_evaluate_partitioned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "kc_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "kc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "kc_get_cache_policy": (C.c_int, []),

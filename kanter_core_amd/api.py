@@ -105,6 +105,38 @@ def get_cache_policy():
     return _lib.load().kc_get_cache_policy()
 
 
+COMM_ID_BYTES = 256
+
+
+def comm_unique_id():
+    """Rank 0: the identifier every rank passes to comm_init (bytes; hand it over by any host-side channel)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(_lib.load().kc_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(rank, world_size, unique_id):
+    """Collective: this process becomes `rank` of `world_size` in the library's RCCL communicator (after init())."""
+    assert len(unique_id) == COMM_ID_BYTES
+    _check(_lib.load().kc_comm_init(int(rank), int(world_size), C.create_string_buffer(unique_id, COMM_ID_BYTES)))
+
+
+def comm_destroy():
+    _check(_lib.load().kc_comm_destroy())
+
+
+def comm_info():
+    r, w = C.c_int(), C.c_int()
+    _check(_lib.load().kc_comm_info(C.byref(r), C.byref(w)))
+    return r.value, w.value
+
+
+def comm_stats():
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _check(_lib.load().kc_comm_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return {"planes_sent": a.value, "planes_received": b.value, "bytes_sent": c.value}
+
+
 def set_option(name, value):
     """Named A/B and test switches (kc_set_option), e.g. "chain1"."""
     _check(_lib.load().kc_set_option(name.encode(), int(value)))
@@ -917,6 +949,24 @@ class LiveGraph:
         _check(_lib.load().kc_live_graph_embed_slot_data_band(self._h, slot_data.image._h, slot_data.slot_id, int(embedded_id),
                                                               int(band_y0), int(full_height)))
         return EmbeddedSlotDataId(embedded_id)
+
+    def exchange(self, transfers):
+        """Moves the slots named by `transfers` = [(node_id, slot_id, src_rank, dst_rank[, level])] between the ranks of the
+        communicator (comm_init) with RCCL, inside the library (csrc/comm.cpp); every rank passes the same list."""
+        from ._lib import kc_transfer
+        n = len(transfers)
+        buf = (kc_transfer * max(n, 1))()
+        for i, t in enumerate(transfers):
+            buf[i].node_id, buf[i].slot_id, buf[i].src_rank, buf[i].dst_rank = int(t[0]), int(t[1]), int(t[2]), int(t[3])
+            buf[i].level = int(t[4]) if len(t) > 4 else 0
+        _check(_lib.load().kc_live_graph_exchange(self._h, buf, n))
+
+    def evaluate_partitioned(self, plan, root_node_id):
+        """The exchange of `plan` (a Partition) followed by `root_node_id` on the plan's home rank: the root's image there,
+        None on the other ranks."""
+        out = C.c_void_p()
+        _check(_lib.load().kc_live_graph_evaluate_partitioned(self._h, plan._h, int(root_node_id), C.byref(out)))
+        return SlotImage(out.value) if out.value else None
 
     def import_slot_data(self, node_id, slot_id, image):
         """The receiving side of a transfer: `image` becomes slot `slot_id` of `node_id`, which is Clean afterwards."""

@@ -109,6 +109,7 @@ try {
     sampler_report();
 #endif
     (void)hipStreamSynchronize(c.stream);
+    (void)comm_destroy();
     specialize_shutdown();
     pool_trim();
     for (auto &us : c.upload_ring) {
@@ -152,6 +153,10 @@ int kc_sync(void)
 try {
     KC_TRY(need_init());
     KC_HIP(hipStreamSynchronize(ctx().stream));
+    {
+        Lock lk(ctx().mu);
+        comm_sync();  // sends still in flight hold references: let them go
+    }
     return KC_OK;
 }
 KC_CATCH
@@ -1347,6 +1352,58 @@ try {
     *count = (uint32_t)p->xfers.size();
     for (uint32_t i = 0; out && i < cap && i < *count; ++i) out[i] = p->xfers[i];
     return KC_OK;
+}
+KC_CATCH
+
+int kc_comm_unique_id(void *id)
+try {
+    return comm_unique_id(id, KC_COMM_ID_BYTES);
+}
+KC_CATCH
+
+int kc_comm_init(int rank, int world_size, const void *id)
+try {
+    Lock lk(ctx().mu);
+    return comm_init(rank, world_size, id, KC_COMM_ID_BYTES);
+}
+KC_CATCH
+
+int kc_comm_destroy(void)
+try {
+    Lock lk(ctx().mu);
+    return comm_destroy();
+}
+KC_CATCH
+
+int kc_comm_info(int *rank, int *world_size)
+try {
+    Lock lk(ctx().mu);
+    comm_info(rank, world_size);
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_comm_stats(uint64_t *planes_sent, uint64_t *planes_received, uint64_t *bytes_sent)
+try {
+    Lock lk(ctx().mu);
+    comm_stats(planes_sent, planes_received, bytes_sent);
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_live_graph_exchange(kc_live_graph *lg, const kc_transfer *transfers, uint32_t count)
+try {
+    LG_LOCK(lg);
+    KC_ARG(transfers || count == 0);
+    return comm_exchange(*lg, transfers, count);
+}
+KC_CATCH
+
+int kc_live_graph_evaluate_partitioned(kc_live_graph *lg, const kc_partition *plan, uint32_t root_node_id, kc_image **out)
+try {
+    LG_LOCK(lg);
+    KC_ARG(plan);
+    return comm_evaluate_partitioned(*lg, *plan, root_node_id, out);
 }
 KC_CATCH
 

@@ -556,6 +556,15 @@ namespace kc {
 int band_evaluate(kc_live_graph &lg, uint32_t root, uint32_t slot, int32_t y0, int32_t y1, kc_image **out);
 int band_source_rows(kc_live_graph &lg, uint32_t root, int32_t y0, int32_t y1, std::vector<kc_band_rows> &out);
 int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out);
+// The exchange (comm.cpp): RCCL, bound at first use.  Callers hold the context lock.
+int comm_unique_id(void *id, size_t bytes);
+int comm_init(int rank, int world, const void *id, size_t bytes);
+int comm_destroy();
+void comm_info(int *rank, int *world);
+void comm_stats(uint64_t *planes_sent, uint64_t *planes_received, uint64_t *bytes_sent);
+int comm_exchange(kc_live_graph &lg, const kc_transfer *t, uint32_t n);
+int comm_evaluate_partitioned(kc_live_graph &lg, const kc_partition &plan, uint32_t root, kc_image **out);
+void comm_sync();
 // process_node, src/node/node_type.rs:213-248: inputs in edge insertion order.
 int process_node(kc_live_graph &lg, const Node &node, const SlotList &inputs, const std::vector<kc_edge> &edges,
                  SlotList &out);

@@ -6,12 +6,15 @@ possible is its readiness rule: a node needs nothing but its parents' slot data 
 ways to shard follow:
 
   * graph level -- `PartitionedEvaluator`: the library's partitioner (csrc/partition.cpp, C ABI
-    kc_live_graph_partition) says which rank evaluates which node and which slots cross a rank boundary; this
-    module moves those slots, plane by plane, with grouped send / recv (over xGMI every producer owns a distinct
-    link into the consumer, so the inbound transfers of a fan-in run concurrently; one slot with consumers on
-    several ranks is sent once per consumer: a broadcast).  A transfer is enqueued right after the kernels that
-    produce it, on RCCL's own stream behind an event of the compute stream, so the hand-off of one branch
-    overlaps the evaluation of the next one on the same rank; nobody's host waits for a GPU.
+    kc_live_graph_partition) says which rank evaluates which node and which slots cross a rank boundary, and the
+    library moves those slots itself (csrc/comm.cpp, C ABI kc_comm_init + kc_live_graph_evaluate_partitioned): RCCL
+    send / recv of whole pitched planes on a communication stream behind an event of the compute stream, the slot's
+    64-byte description on a second communicator, constants as scalars, one slot with consumers on several ranks
+    sent once per consumer.  Over xGMI every producer owns a distinct link into the consumer, so the inbound
+    transfers of a fan-in run concurrently, and the hand-off of one branch overlaps the evaluation of the next one
+    on the same rank; nobody's host waits for plane data.  With the `nccl` backend this class is a thin caller of
+    that path (torch.distributed only carries the communicator's identifier, once).  The host-side loop below is
+    what the CPU tests (gloo, a host slot store) and the several-ranks-on-one-GPU rehearsal run.
   * data level -- `row_bands`: pointwise graphs split by rows with no exchange at all; graphs with resize or
     HeightToNormal nodes through kc_live_graph_await_clean_band, which widens each band by the halo rows the
     node types below it need (bands.cpp).
@@ -48,6 +51,13 @@ class DeviceBackend:
 
     def __init__(self, live_graph, device):
         self.lg, self.device, self.L = live_graph, device, _lib.load()
+        # The library enqueues on its own stream, torch on its current one: nothing orders the two unless they are the
+        # same stream.  This backend reads planes the library has only enqueued (export) and writes planes the library's
+        # queued kernels may still read (recycled pool blocks), so both sides are put on ONE dedicated stream -- never the
+        # legacy default stream, which other non-blocking streams do not wait for.
+        cur = torch.cuda.current_stream(device)
+        self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(device)
+        kc.set_stream(self.stream.cuda_stream)
 
     def _plane_tensor(self, handle, h):
         ptr, pitch = C.c_void_p(), C.c_size_t()
@@ -147,8 +157,16 @@ class PartitionedEvaluator:
             backend = backend(self.plan, self.rank)  # a factory: the slot store may depend on the placement
         self.backend = backend
         # headers (a few dozen bytes) go over a host-side group so that posting a receive never waits for a GPU
-        self.header_group = header_group if header_group is not None else group
         self.stage_through_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # the native path: RCCL inside the library.  Only with the library as slot store and one rank per GPU.
+        self.native = isinstance(backend, DeviceBackend) and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if self.native and kc.comm_info() == (0, 0):
+            box = [kc.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=self._global(0), group=group)
+            kc.comm_init(self.rank, self.world, box[0])
+        if header_group is None and dist.is_initialized() and dist.get_backend(group) == "nccl" and not self.native:
+            header_group = dist.new_group(backend="gloo")  # pickled headers over nccl would go through GPU tensors and host syncs
+        self.header_group = header_group if header_group is not None else group
         self.stats = {}
 
     def transfers_by_slot(self):
@@ -162,6 +180,22 @@ class PartitionedEvaluator:
         return out
 
     def evaluate(self):
+        be, rank = self.backend, self.rank
+        if self.native:
+            t_start = time.perf_counter()
+            s0 = kc.comm_stats()
+            result = self.lg.evaluate_partitioned(self.plan, self.root)
+            s1 = kc.comm_stats()
+            self.stats = {"rank": rank, "host_total_s": time.perf_counter() - t_start, "native": True,
+                          "planes_sent": s1["planes_sent"] - s0["planes_sent"],
+                          "planes_received": s1["planes_received"] - s0["planes_received"],
+                          "bytes_sent": s1["bytes_sent"] - s0["bytes_sent"]}
+            return result
+        import contextlib
+        with (torch.cuda.stream(be.stream) if getattr(be, "stream", None) is not None else contextlib.nullcontext()):
+            return self._evaluate_host_loop()
+
+    def _evaluate_host_loop(self):
         be, rank = self.backend, self.rank
         t_start = time.perf_counter()
         t_compute = t_exchange = 0.0
