@@ -166,6 +166,19 @@ def main():
         g = make(False)
         band_keep = []
 
+        def make_cold(i):
+            # an independent copy of the workload on its own inputs (see "cold" below)
+            ia = kc.SlotImage.from_planes([splitmix_plane(SEED_A + 0x1000 * (i + 1), c, S, S) for c in range(4)])
+            ib = kc.SlotImage.from_planes([splitmix_plane(SEED_B + 0x1000 * (i + 1), c, S, S) for c in range(4)])
+            lgc = tp.new_live_graph()
+            ca, cb = embed(kc, lgc, ia, 0), embed(kc, lgc, ib, 1)
+            cfirst, clast = add_chain(kc, lgc, ca, cb, N)
+
+            def cstep():
+                lgc.connect(ca, cfirst, 0, 0)
+                lgc.await_clean(clast)
+            return cstep
+
         def step(gg=g):
             lg, na, first, last = gg
             if band is not None:
@@ -195,6 +208,20 @@ def main():
             lg.connect(na, m, 0, 0)
             lg.await_clean(m)
 
+        def make_cold(i):
+            ia = kc.SlotImage.from_planes([splitmix_plane(SEED_A + 0x1000 * (i + 1), c, S, S) for c in range(4)])
+            ib = kc.SlotImage.from_planes([splitmix_plane(SEED_B + 0x1000 * (i + 1), c, S, S) for c in range(4)])
+            lgc = tp.new_live_graph()
+            ca, cb = embed(kc, lgc, ia, 0), embed(kc, lgc, ib, 1)
+            cm = lgc.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)))
+            lgc.connect(ca, cm, 0, 0)
+            lgc.connect(cb, cm, 0, 1)
+
+            def cstep():
+                lgc.connect(ca, cm, 0, 0)
+                lgc.await_clean(cm)
+            return cstep
+
         node_px, alg_bytes, kernel = float(S) * S, 36.0 * S * S, "chain_kernel<2,4,0>"
         desc = "single Mix(Add) node, two %dx%d f32x4 inputs, BASELINE config #1" % (S, S)
     elif args.workload == "resize_blend":
@@ -217,6 +244,22 @@ def main():
         def step():
             lg.connect(na, n1, 0, 0)
             lg.await_clean(n3)
+
+        def make_cold(i):
+            ia = kc.SlotImage.from_planes([splitmix_plane(SEED_A + 0x1000 * (i + 1), c, S, S) for c in range(4)])
+            ib = kc.SlotImage.from_planes([splitmix_plane(SEED_B + 0x1000 * (i + 1), c, s_small, s_small) for c in range(4)])
+            lgc = tp.new_live_graph()
+            ca, cb = embed(kc, lgc, ia, 0), embed(kc, lgc, ib, 1)
+            c1 = lgc.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)))
+            c2 = lgc.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Multiply)))
+            c3 = lgc.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Subtract)))
+            for (a_, b_, s_) in ((ca, c1, 0), (cb, c1, 1), (c1, c2, 0), (ca, c2, 1), (c2, c3, 0), (cb, c3, 1)):
+                lgc.connect(a_, b_, 0, s_)
+
+            def cstep():
+                lgc.connect(ca, c1, 0, 0)
+                lgc.await_clean(c3)
+            return cstep
 
         node_px = 3.0 * S * S
         # fused: the resampled B never exists in HBM.  One launch reads R,G,B of A (12 B/px) and of the
@@ -378,28 +421,33 @@ def main():
         kernel = "kc_chain_<hash> (the chain program compiled to straight-line code at run time, csrc/specialize.cpp; " + kernel + " = the interpreter, first sightings only)"
     main_step_us = step_spread(step, max(20, min(args.steps, 100)))
     total_px = node_px
+    job_bytes, job_dev_s = alg_bytes, dev_s
     if world > 1:
-        t = torch.tensor([wall, node_px], device=red_dev, dtype=torch.float64)
+        t = torch.tensor([wall, node_px, alg_bytes, dev_s], device=red_dev, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         wall, total_px = float(tmax[0].item()), float(t[1].item())
+        job_bytes, job_dev_s = float(t[2].item()), float(tmax[3].item())
 
     value = total_px * args.steps / wall / 1e6  # whole-job node-Mpix/s
-    per_step_s = dev_s / args.steps             # HIP events on the launch stream over the timed region
+    per_step_s = dev_s / args.steps             # HIP events on the launch stream over the timed region (this rank)
     launches_per_step = launches / args.steps
-    achieved = alg_bytes / per_step_s / 1e9
+    # achieved = the job's algorithmic bytes / time / (n_gpu x 8 TB/s) -- all ranks' bytes over the slowest
+    # rank's time (N = 1: this rank's)
+    achieved = job_bytes / (job_dev_s / args.steps) / 1e9
+    peak_gbs = HBM_PEAK_GBS * world
     # HBM traffic by PMC counters is collected in separate rocprofv3 --pmc passes (profiles/run_pmc.sh), never inside
     # this run: the figure below is read from the committed capture and labelled with its source; it is dropped when
     # the capture is of another kernel than the one this run launched.
     traffic = traffic_source = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_resize_chain_kernel.json" if args.workload == "resize_blend" else "r02_pmc_chain_kernel.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_upsample_chain_kernel.json" if args.workload == "resize_blend" else "r03_pmc_chain_kernel.json")
     if os.path.exists(pmc) and S == 4096 and ((args.workload == "chain32" and N == 32 and band is None) or args.workload == "resize_blend"):
         try:
             with open(pmc) as f:
                 cap = json.load(f)
             ran_specialized = bool(kc.specialize_stats()["specialized_launches"])
-            if args.workload == "resize_blend" or (("kc_chain_" in cap.get("kernel", "")) == ran_specialized):
+            if ("kc_upchain_" in cap.get("kernel", "") and ran_specialized) if args.workload == "resize_blend" else (("kc_chain_" in cap.get("kernel", "")) == ran_specialized):
                 traffic = cap.get("hbm_bytes_per_launch")
                 traffic_source = "%s (kernel %s; %s)" % (os.path.relpath(pmc, ROOT), cap.get("kernel"), cap.get("captured") or "capture note missing")
         except Exception:
@@ -423,14 +471,18 @@ def main():
         "config": {
             "workload": desc, "graph_nodes": N if args.workload == "chain32" else None, "width": S, "height": S,
             "channels": 4, "use_cache": False,
+            "series": ("%s at %dx%d: the line for --gpus N of this workload and size; N = 1 runs the same graph through the same path"
+                       % ("chain32_rows (one graph split by row bands, strong scaling)" if band is not None else args.workload, S, S)),
+            "cache_policy": kc.get_cache_policy(),
             "parallelism": (("row bands of one graph through kc_live_graph_evaluate_band, no exchange" if band is not None else
                              "independent graph per GPU") if args.workload != "fanin"
                             else "branches placed by the library's partitioner + RCCL send/recv to the home rank")
             if world > 1 else "single GPU",
         },
         "roofline": {
-            "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": peak_gbs, "unit": "GB/s",
+            "frac": round(achieved / peak_gbs, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "scope": "whole job: all ranks' algorithmic bytes / slowest rank's time / (n_gpus x 8 TB/s)" if world > 1 else "one GPU",
             "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_step, 1.0) if launches_per_step else alg_bytes,
             "algorithmic_bytes_per_step": alg_bytes, "closed_form_bytes_per_step": formula_bytes,
             "kernel_us": round(per_step_s / max(launches_per_step, 1.0) * 1e6, 2),
@@ -442,6 +494,32 @@ def main():
             "host_us_per_step_first5": [round(x, 1) for x in main_host_us[:5]], "host_us_per_step_median": round(sorted(main_host_us)[len(main_host_us) // 2], 1),
         },
     }
+
+    if rank == 0 and world == 1 and band is None and args.workload in ("chain32", "mix1", "resize_blend") and not args.no_extras:
+        # ---- cold: nothing a step touches can still be in the 256 MB Infinity Cache ----
+        # The timed region above re-evaluates ONE graph on the same inputs (what an editor does, and what the contract asks
+        # for); with the cache policy (csrc/runtime.cpp, chain_cache_policy) one long-lived input of it stays in the Infinity
+        # Cache from step to step.  Here four copies of the workload on different inputs are stepped in rotation, so every
+        # step reads inputs and writes results that were last touched > 1.5 GB of traffic ago: HBM serves everything.
+        cold_steps = [step] + [make_cold(i) for i in range(3)]
+        rr = [0]
+
+        def cold_step():
+            cold_steps[rr[0] % len(cold_steps)]()
+            rr[0] += 1
+
+        kc_steps = max(20, min(args.steps, 100)) // len(cold_steps) * len(cold_steps)
+        wall_c, dev_c, launches_c = timed(cold_step, kc_steps, 2 * len(cold_steps), sync_ranks=False)
+        out["roofline"]["cold"] = {
+            "kernel_us": round(dev_c / max(launches_c, 1) * 1e6, 2), "frac": round(counted[0] * kc_steps / dev_c / 1e9 / HBM_PEAK_GBS, 4),
+            "steps": kc_steps,
+            "how": "4 instances of the workload on different inputs evaluated in rotation: inputs and results of a step were last "
+                   "touched more than 1.5 GB of traffic earlier, so the 256 MB Infinity Cache holds none of them",
+        }
+        out["roofline"]["warm_note"] = ("frac is the contract's measurement: one graph re-evaluated on resident inputs; with "
+                                        "cache_policy = 1 a long-lived input can stay in the Infinity Cache between steps, which is how "
+                                        "frac can exceed what HBM alone delivers (~0.80); cold.frac excludes that")
+        del cold_steps
 
     if rank == 0 and args.workload == "chain32" and not args.no_extras and band is None:
         # ---- the same graph with every node materialised (use_cache = true): N launches per step ----
@@ -531,6 +609,48 @@ def main():
         nan_ok = lambda x, y: (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))  # noqa: E731
         mism = int(sum((~nan_ok(x, y)).sum() for x, y in zip(got, ref)))
         out["parity"] = {"checked_pixels": S * S * 4, "bit_mismatches": mism}
+
+    if band is not None and not args.no_cpu_baseline:
+        # parity of the row-band path on every rank: three 32-row crops of this rank's band (its first, middle and last rows)
+        # against the oracle on the same rows of the inputs -- the graph is pointwise, so a crop's result depends on nothing else
+        from oracle import oracle as orc
+        got = band_keep[0].planes()
+        mism, checked = 0, 0
+        for r0 in sorted({0, max(0, rows // 2 - 16), max(0, rows - 32)}):
+            r1 = min(rows, r0 + 32)
+            ref = orc.chain32([p[r0:r1] for p in host_a], [p[r0:r1] for p in host_b], N)
+            mism += int(sum((x[r0:r1].view(np.uint32) != np.ascontiguousarray(y).view(np.uint32)).sum() for x, y in zip(got, ref)))
+            checked += (r1 - r0) * S * 4
+        if world > 1:
+            t = torch.tensor([mism, checked], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            mism, checked = int(t[0].item()), int(t[1].item())
+        out["parity"] = {"checked_pixels": checked, "bit_mismatches": mism,
+                         "how": "3 crops of 32 rows per rank against the oracle on the same rows, summed over the ranks"}
+
+    if args.workload == "fanin" and world > 1 and not args.no_cpu_baseline:
+        # parity of the partitioned evaluation: the home rank's result against the oracle on three 32-row crops (the graph
+        # is pointwise); every rank learns the verdict
+        verdict = torch.zeros(2, device=red_dev, dtype=torch.float64)
+        if rank == ev.plan.home:
+            from oracle import oracle as orc
+            got = keep[0].planes()
+            for r0 in (0, S // 2 - 16, S - 32):
+                parts = []
+                for k in range(n_branches):
+                    ha = [splitmix_rows(0x5EED0100 + k, c, S, S, r0, r0 + 32) for c in range(3)]
+                    hb = [splitmix_rows(0x5EED0200 + k, c, S, S, r0, r0 + 32) for c in range(3)]
+                    parts.append(orc.chain32(ha, hb, sub_nodes)[:3])
+                while len(parts) > 1:
+                    nxt = [[orc.mix_plane("Add", parts[i][c], parts[i + 1][c]) for c in range(3)] for i in range(0, len(parts) - 1, 2)]
+                    if len(parts) & 1:
+                        nxt.append(parts[-1])
+                    parts = nxt
+                verdict[0] += int(sum((got[c][r0:r0 + 32].view(np.uint32) != np.ascontiguousarray(parts[0][c]).view(np.uint32)).sum() for c in range(3)))
+                verdict[1] += 32 * S * 3
+        dist.all_reduce(verdict, op=dist.ReduceOp.SUM)
+        out["parity"] = {"checked_pixels": int(verdict[1].item()), "bit_mismatches": int(verdict[0].item()),
+                         "how": "the home rank's result, 3 crops of 32 rows, against the oracle"}
 
     if args.workload == "fanin":
         st = dict(ev.stats)
