@@ -140,7 +140,10 @@ KC_API int kc_set_cache_policy(int mode);
 KC_API int kc_get_cache_policy(void);
 /* Named A/B and test switches (results are identical whatever they say; unknown names are refused):
  *   "chain1" 1 (default): a single Mix step runs its ahead-of-time straight-line kernel; 0: the step interpreter / the
- *   run-time specialiser, as longer programs do. */
+ *   run-time specialiser, as longer programs do;
+ *   "replay" 1 (default): an evaluation that repeats the previous one of the same node exactly (same graph by content, same
+ *   node states, same slot data and embedded images by identity) skips the node-by-node walk of src/engine.rs:200-307 and
+ *   re-issues the recorded launch; 0: always walk. */
 KC_API int kc_set_option(const char *name, int value);
 KC_API int kc_get_option(const char *name, int *value);
 /* Diagnostics (host only, works without a device): the structure the integer-ratio up-sampling kernels rely on,
@@ -160,7 +163,7 @@ KC_API int kc_stats_algorithmic_bytes(uint64_t *bytes);
 /* Named event counters since kc_init (tests and profiling: which kernel family a call went through).  Unknown names
  * read 0.  Names: "upsample_launches", "upsample_chain_launches" (the integer-ratio up-sampling kernels),
  * "resize_chain_launches" (the general fused resample + chain kernel), "chain1_launches" (one-step programs through the
- * ahead-of-time kernels). */
+ * ahead-of-time kernels), "replayed_evaluations". */
 KC_API int kc_stats_counter(const char *name, uint64_t *value);
 KC_API int kc_pool_trim(void);
 /* Run-time specialisation of the fused Mix-chain kernel.  A chain of N Mix nodes (src/node/mix.rs:136-192

@@ -231,6 +231,7 @@ try {
     KC_ARG(name);
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
     if (std::strcmp(name, "chain1") == 0) ctx().chain1 = value != 0;
+    else if (std::strcmp(name, "replay") == 0) ctx().replay = value != 0;
     else {
         set_error(std::string("unknown option ") + name);
         return KC_ERR_INVALID_ARG;
@@ -243,6 +244,7 @@ int kc_get_option(const char *name, int *value)
 try {
     KC_ARG(name && value);
     if (std::strcmp(name, "chain1") == 0) *value = ctx().chain1 ? 1 : 0;
+    else if (std::strcmp(name, "replay") == 0) *value = ctx().replay ? 1 : 0;
     else {
         set_error(std::string("unknown option ") + name);
         return KC_ERR_INVALID_ARG;

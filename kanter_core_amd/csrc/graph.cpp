@@ -153,6 +153,28 @@ void NodeGraph::appended_node(bool index_was_current)
     idx.n_nodes = nodes.size();
 }
 
+// Removing an edge from a graph whose index is current patches the index too (re-plugging an input of a 32-node graph used to
+// cost a rebuild of three hash tables of vectors: most of a connect()).  Call after edges.erase with the erased edge.
+void NodeGraph::erased_edge(const kc_edge &e, bool index_was_current)
+{
+    touch();
+    if (!index_was_current) return;
+    auto drop = [&](std::vector<kc_edge> &v) {
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].output_id == e.output_id && v[i].input_id == e.input_id && v[i].output_slot == e.output_slot && v[i].input_slot == e.input_slot) {
+                v.erase(v.begin() + (long)i);
+                return;
+            }
+    };
+    auto a = idx.in_edges.find(e.input_id);
+    auto b = idx.out_edges.find(e.output_id);
+    if (a == idx.in_edges.end() || b == idx.out_edges.end()) return;  // cannot be: leave the index stale, it is rebuilt on use
+    drop(a->second);
+    drop(b->second);
+    idx.version = version;
+    idx.n_edges = edges.size();
+}
+
 void NodeGraph::appended_edge(bool index_was_current)
 {
     touch();
@@ -300,6 +322,13 @@ int NodeGraph::connect(uint32_t on, uint32_t in, uint32_t os, uint32_t is)
     // :416-446
     const Node *o = find(on), *i = find(in);
     if (!o || !i) return KC_ERR_INVALID_NODE_ID;
+    // Re-plugging the edge that is already the newest one (an editor re-connecting the same cable, bench.py's step): the
+    // reference removes it and appends it again, which leaves `edges` exactly as it is -- nothing to do, and above all no
+    // reason to throw the index away.  (Its slots were checked when it was first connected.)
+    if (!edges.empty()) {
+        const kc_edge &l = edges.back();
+        if (l.output_id == on && l.input_id == in && l.output_slot == os && l.input_slot == is) return KC_OK;
+    }
     int ot, it;
     KC_TRY(slot_type_of(node_output_slots(*o), os, &ot));
     KC_TRY(slot_type_of(node_input_slots(*i), is, &it));
@@ -319,8 +348,10 @@ int NodeGraph::remove_edge(kc_edge e)
         const kc_edge &c = edges[i];
         if (c.output_id == e.output_id && c.input_id == e.input_id && c.output_slot == e.output_slot && c.input_slot == e.input_slot) {
             if (!find(e.input_id)) return KC_ERR_INVALID_NODE_ID;
+            const bool cur = index_is_current();
+            const kc_edge gone = c;
             edges.erase(edges.begin() + (long)i);
-            touch();
+            erased_edge(gone, cur);
             return KC_OK;
         }
     }
@@ -364,8 +395,10 @@ int NodeGraph::disconnect_slot(uint32_t id, int side, uint32_t slot, std::vector
                                                : (e.output_id == id && e.output_slot == slot);
         if (hit) {
             if (removed) removed->insert(removed->begin(), e);
+            const bool cur = index_is_current();
+            const kc_edge gone = e;
             edges.erase(edges.begin() + (long)i);
-            touch();
+            erased_edge(gone, cur);
             any = true;
         }
     }
@@ -711,6 +744,7 @@ using namespace kc;
 
 kc_live_graph::~kc_live_graph()
 {
+    replay_clear();
     clear_data();
     for (auto &e : embedded) image_release(e.image);
     for (auto &i : input_slot_datas) image_release(i.image);
@@ -767,14 +801,16 @@ int kc_live_graph::set_state(uint32_t id, int st)
         changed.insert(id);
         return KC_OK;
     }
-    std::vector<uint32_t> work{ id };
+    SmallVec<uint32_t, 64> work;
+    work.push_back(id);
     while (!work.empty()) {
-        const uint32_t n = work.back();
-        work.pop_back();
-        int cur;
-        KC_TRY(state_of(n, &cur));
+        const uint32_t n = work[work.size() - 1];
+        work.erase_at(work.size() - 1);
+        auto st = node_state.find(n);
+        if (st == node_state.end()) return KC_ERR_INVALID_NODE_ID;
+        const int cur = st->second;
         if (cur == KC_STATE_DIRTY) continue;
-        node_state[n] = cur == KC_STATE_PROCESSING ? KC_STATE_PROCESSING_DIRTY : KC_STATE_DIRTY;
+        st->second = cur == KC_STATE_PROCESSING ? KC_STATE_PROCESSING_DIRTY : KC_STATE_DIRTY;
         changed.insert(n);
         // straight from the edge index: a child listed twice (two edges from n) is skipped by the state test above
         // (get_children would allocate, sort and de-duplicate a vector per node: a third of a connect() on a 32-node chain)
@@ -1016,6 +1052,18 @@ int kc_live_graph::await_clean(uint32_t id)
 {
     KC_PROF("await_clean_total");
     if (!g.find(id)) return KC_ERR_INVALID_NODE_ID;
+    // an evaluation that repeats the recorded one exactly is replayed without the walk (replay.cpp)
+    bool replayed = false;
+    KC_TRY(replay_try(*this, id, &replayed));
+    if (replayed) return KC_OK;
+    ReplayRecorder *rec = replay_begin(*this, id);
+    const int s = await_clean_walk(id);
+    replay_end(*this, id, rec, s);
+    return s;
+}
+
+int kc_live_graph::await_clean_walk(uint32_t id)
+{
     ResizeMemoScope memo;
     if (auto_update) KC_TRY(update());
     KC_TRY(ensure_clean(id));

@@ -176,13 +176,26 @@ struct TapsEntry {
     TapsDev dev{};
 };
 
+// What chain_launch leaves behind while an evaluation is being recorded for replay (replay.cpp).
+struct ReplayCapture {
+    int n_launch = 0;
+    bool ok = true;
+    ChainProgram prog;
+    int batch = 0, mode = 0;
+    uint32_t in_refs[KC_CHAIN_MAX_IN] = { 0, 0, 0, 0 };
+    uint32_t w = 0, h = 0;
+    kc_plane *planes[KC_CHAIN_MAX_BATCH] = { nullptr, nullptr, nullptr, nullptr };  // the lazy planes the launch made resident
+};
+
 struct Context {
     std::recursive_mutex mu;
+    ReplayCapture *capture = nullptr;
     bool inited = false;
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     bool fusion = true;
+    bool replay = true;  // an evaluation that repeats the recorded one is replayed without the walk (kc_set_option("replay", 0); env KC_REPLAY)
     bool chain1 = true;  // one-step programs run the ahead-of-time kernels of chain1.hip (kc_set_option("chain1", 0): interpreter / specialiser, A/B and tests)
     int cache_policy = 1;  // 1: launches whose streams exceed the Infinity Cache mark them nontemporal (cache_policy_mask); 0: plain loads / stores (KC_CACHE_POLICY, kc_set_cache_policy)
     int max_blocks = 4096;
@@ -315,6 +328,8 @@ hipError_t launch_chain_specialized(const ChainProgram &P, int batch, hipStream_
 // Which streams of a launch are marked nontemporal: `in_bytes` / `out_bytes` = what the launch reads from its n_resident
 // full-size input planes / writes, summed over its channels.  Returns the ChainProgram::nt_mask bits.
 uint32_t cache_policy_mask(uint64_t in_bytes, uint64_t out_bytes, uint32_t n_resident);
+uint32_t chain_cache_policy(const uint32_t *refs, uint32_t n, uint64_t stream_bytes, uint64_t out_bytes);
+hipError_t chain_dispatch(ChainProgram &P, int batch, int mode, uint32_t w, uint32_t h, size_t out_pitch_bytes);
 hipError_t launch_upsample_chain_specialized(const ChainProgram &P, int batch, const UpsampleArgs &U, hipStream_t s, bool *launched);
 int specialize_set_mode(int mode, int after);  // 0 off, 1 background compile after `after` sightings, 2 compile at once
 int specialize_get_mode();
@@ -381,6 +396,7 @@ struct NodeGraph {
     bool index_is_current() const;
     void appended_node(bool index_was_current);  // after nodes.push_back: bumps the version, patches a current index
     void appended_edge(bool index_was_current);  // after edges.push_back
+    void erased_edge(const kc_edge &e, bool index_was_current);  // after edges.erase
     const std::vector<kc_edge> &edges_into(uint32_t id) const;
     const std::vector<kc_edge> &edges_out_of(uint32_t id) const;
 
@@ -522,6 +538,9 @@ struct kc_live_graph {
     bool use_cache = false;
     std::string base_dir;
     int depth = 0;  // nesting depth of Graph nodes (recursion guard)
+    struct ReplayEntry;
+    ReplayEntry *replay = nullptr;  // the last evaluation that qualified, recorded for replay (replay.cpp)
+    void replay_clear();
 
     ~kc_live_graph();
     void clear_data();
@@ -540,6 +559,7 @@ struct kc_live_graph {
     int ensure_clean(uint32_t id);
     int import_slot_data(uint32_t node, uint32_t slot, kc_image *image);  // partition.cpp
     int await_clean(uint32_t id);
+    int await_clean_walk(uint32_t id);
     int update();
     int process_one(uint32_t id);
 };
@@ -556,6 +576,11 @@ namespace kc {
 int band_evaluate(kc_live_graph &lg, uint32_t root, uint32_t slot, int32_t y0, int32_t y1, kc_image **out);
 int band_source_rows(kc_live_graph &lg, uint32_t root, int32_t y0, int32_t y1, std::vector<kc_band_rows> &out);
 int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out);
+// Replay of a recorded evaluation (replay.cpp)
+struct ReplayRecorder;
+int replay_try(kc_live_graph &lg, uint32_t id, bool *hit);
+ReplayRecorder *replay_begin(kc_live_graph &lg, uint32_t id);
+void replay_end(kc_live_graph &lg, uint32_t id, ReplayRecorder *r, int s);
 // The exchange (comm.cpp): RCCL, bound at first use.  Callers hold the context lock.
 int comm_unique_id(void *id, size_t bytes);
 int comm_init(int rank, int world, const void *id, size_t bytes);

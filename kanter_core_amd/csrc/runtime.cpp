@@ -484,7 +484,7 @@ static int chain_prepare(kc_plane *p)
 // only if it fits beside them.  Measured on config #1's traffic (profiles/tilecopy.hip add2, r03_tilecopy4.txt): plain
 // 102.9 us, everything streamed 92.6 us, one input kept 84.2 us -- and keeping the RESULT instead is 88.7 us when it goes
 // to the same block every time but 98.9 us when a graph still holds its previous result, which is the usual case.
-static uint32_t chain_cache_policy(const uint32_t *refs, uint32_t n, uint64_t stream_bytes, uint64_t out_bytes)
+uint32_t chain_cache_policy(const uint32_t *refs, uint32_t n, uint64_t stream_bytes, uint64_t out_bytes)
 {
     if (!ctx().cache_policy) return 0;
     static const long forced = std::getenv("KC_NT_FORCE") ? std::strtol(std::getenv("KC_NT_FORCE"), nullptr, 0) : -1;  // tuning: this mask for every launch
@@ -517,13 +517,69 @@ uint32_t cache_policy_mask(uint64_t in_bytes, uint64_t out_bytes, uint32_t n_res
     return mask;
 }
 
+// Launches a (non-resampling) chain program whose inputs and outputs are set: the ahead-of-time kernel of a one-step
+// program, else the kernel compiled for the program at run time if there is one, else the interpreter.  Shared by
+// chain_launch and by the replay of a recorded evaluation (replay.cpp).
+hipError_t chain_dispatch(ChainProgram &P, int batch, int mode, uint32_t w, uint32_t h, size_t out_pitch_bytes)
+{
+    Context &c = ctx();
+    const uint32_t row_units = (w + 3) / 4;
+    bool launched = false;
+    // Rows can be flattened into one run when every plane is dense (pitch == 16 * row_units).
+    bool dense = (size_t)row_units * 16 == out_pitch_bytes;
+    for (int b = 0; b < batch && dense; ++b)
+        for (uint32_t k = 0; k < P.n_in; ++k)
+            if (P.in_pitch[b][k] != row_units) dense = false;
+    if (dense) {
+        P.rows = 1;
+        P.row_units = row_units * h;
+    } else {
+        P.rows = h;
+        P.row_units = row_units;
+    }
+    if (!launched && P.n_ops == 1 && c.chain1) {
+        // a single Mix step: its ahead-of-time straight-line kernel (chain1.hip)
+        Chain1Args a{};
+        const uint32_t w0 = P.step[0][0].a.word, from = w0 >> 8;
+        for (int b = 0; b < batch; ++b) {
+            if (P.start_src >= 0) {
+                a.start[b] = P.in[b][P.start_src];
+                a.start_pitch[b] = P.in_pitch[b][P.start_src];
+            }
+            a.start_c[b] = P.start_c[b];
+            if (from) {
+                a.operand[b] = P.in[b][from - 1];
+                a.operand_pitch[b] = P.in_pitch[b][from - 1];
+            }
+            a.operand_c[b] = a.c[b] = P.step[b][0].a.c;
+            a.out[b] = P.out[b];
+            a.out_pitch[b] = P.out_pitch[b];
+        }
+        a.rows = P.rows;
+        a.row_units = P.row_units;
+        const unsigned nt = (P.start_src >= 0 && (P.nt_mask >> P.start_src & 1u) ? 1u : 0u) | (from && (P.nt_mask >> (from - 1) & 1u) ? 2u : 0u) |
+                            (P.nt_mask & 0x100u ? 4u : 0u);
+        hipError_t e = launch_chain1(a, batch, (int)(w0 & 0xffu), nt, c.stream);
+        if (e != hipSuccess) return e;
+        c.counters["chain1_launches"]++;
+        launched = true;
+    }
+    if (!launched) {
+        // a program-specialised straight-line kernel if one has been compiled (specialize.cpp) ...
+        hipError_t e = launch_chain_specialized(P, batch, c.stream, &launched);
+        // ... otherwise the interpreter
+        if (e == hipSuccess && !launched) e = launch_chain(P, batch, mode, c.max_blocks, c.chain_unroll, c.stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 {
     KC_PROF("chain_launch");
     Context &c = ctx();
     ChainProgram &P = bc.prog;
     const kc_plane *p0 = planes[0];
-    const uint32_t row_units = (p0->w + 3) / 4;
     // Outputs are fresh pool planes, all with the pitch of their width.
     std::vector<kc_plane *> outs(batch, nullptr);
     for (int b = 0; b < batch; ++b) {
@@ -551,53 +607,8 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
             return KC_RETRY_CHAIN;
         }
     }
-    // Rows can be flattened into one run when every plane is dense (pitch == 16 * row_units).
-    bool dense = (size_t)row_units * 16 == outs[0]->pitch;
-    for (int b = 0; b < batch && dense; ++b)
-        for (uint32_t k = 0; k < P.n_in; ++k)
-            if (P.in_pitch[b][k] != row_units) dense = false;
-    if (dense) {
-        P.rows = 1;
-        P.row_units = row_units * p0->h;
-    } else {
-        P.rows = p0->h;
-        P.row_units = row_units;
-    }
-    if (!launched && P.n_ops == 1 && c.chain1) {
-        // a single Mix step: its ahead-of-time straight-line kernel (chain1.hip)
-        Chain1Args a{};
-        const uint32_t w0 = P.step[0][0].a.word, from = w0 >> 8;
-        for (int b = 0; b < batch; ++b) {
-            if (P.start_src >= 0) {
-                a.start[b] = P.in[b][P.start_src];
-                a.start_pitch[b] = P.in_pitch[b][P.start_src];
-            }
-            a.start_c[b] = P.start_c[b];
-            if (from) {
-                a.operand[b] = P.in[b][from - 1];
-                a.operand_pitch[b] = P.in_pitch[b][from - 1];
-            }
-            a.operand_c[b] = a.c[b] = P.step[b][0].a.c;
-            a.out[b] = P.out[b];
-            a.out_pitch[b] = P.out_pitch[b];
-        }
-        a.rows = P.rows;
-        a.row_units = P.row_units;
-        const unsigned nt = (P.start_src >= 0 && (P.nt_mask >> P.start_src & 1u) ? 1u : 0u) | (from && (P.nt_mask >> (from - 1) & 1u) ? 2u : 0u) |
-                            (P.nt_mask & 0x100u ? 4u : 0u);
-        hipError_t e = launch_chain1(a, batch, (int)(w0 & 0xffu), nt, c.stream);
-        if (e != hipSuccess) {
-            for (auto *o : outs) plane_release(o);
-            return hip_fail(e, "launch_chain1");
-        }
-        c.counters["chain1_launches"]++;
-        launched = true;
-    }
     if (!launched) {
-        // a program-specialised straight-line kernel if one has been compiled (specialize.cpp) ...
-        hipError_t e = launch_chain_specialized(P, batch, c.stream, &launched);
-        // ... otherwise the interpreter
-        if (e == hipSuccess && !launched) e = launch_chain(P, batch, bc.mode, c.max_blocks, c.chain_unroll, c.stream);
+        hipError_t e = chain_dispatch(P, batch, bc.mode, p0->w, p0->h, outs[0]->pitch);
         if (e != hipSuccess) {
             for (auto *o : outs) plane_release(o);
             return hip_fail(e, "launch_chain");
@@ -614,6 +625,20 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
             if (bc.sampled[b]) bytes += 4 * (uint64_t)bc.sampled[b]->rz_src->w * bc.sampled[b]->rz_src->h;
         }
         c.alg_bytes += bytes;
+    }
+    if (c.capture) {  // an evaluation is being recorded for replay (replay.cpp)
+        ReplayCapture &cap = *c.capture;
+        if (bc.sampled[0] || cap.n_launch >= 1) cap.ok = false;  // one plain chain launch is what a recording may hold
+        else {
+            cap.prog = P;
+            cap.batch = batch;
+            cap.mode = bc.mode;
+            std::memcpy(cap.in_refs, bc.in_refs, sizeof cap.in_refs);
+            cap.w = p0->w;
+            cap.h = p0->h;
+            for (int b = 0; b < batch; ++b) cap.planes[b] = planes[b];
+        }
+        cap.n_launch++;
     }
     for (int b = 0; b < batch; ++b) {
         kc_plane *p = planes[b];

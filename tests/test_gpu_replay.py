@@ -1,0 +1,176 @@
+"""Replay of a recorded evaluation (csrc/replay.cpp): an await_clean that repeats the previous one of the same node exactly
+skips the node-by-node walk (the reference's src/engine.rs:200-307) and re-issues the recorded launch.  What must hold:
+  * replayed results are the oracle's, bit for bit, every time;
+  * everything observable afterwards (node states, which nodes hold slot data, the changed set) is what the walk leaves;
+  * any edit -- a Mix type, an edge, an embedded image, a value, use_cache, a new node -- is seen: the next evaluation walks."""
+import numpy as np
+import pytest
+
+from util import SEED_A, SEED_B, assert_planes, bit_equal, splitmix_plane, synthetic_rgba
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kc():
+    import kanter_core_amd as kc
+    kc.init(0)
+    yield kc
+    kc.set_option("replay", 1)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as orc
+    return orc
+
+
+def chain_graph(kc, a, b, n):
+    """The BASELINE chain (bench.py add_chain) on embedded images a, b."""
+    tp = kc.TextureProcessor.new()
+    lg = tp.new_live_graph()
+    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(a)), 0)
+    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(b)), 1)
+    na = lg.add_node(kc.Node.new(kc.NodeType.Embed(0)))
+    nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(1)))
+    one = lg.add_node(kc.Node.new(kc.NodeType.Value(1.0)))
+    white = lg.add_node(kc.Node.new(kc.NodeType.CombineRgba))
+    for s in range(3):
+        lg.connect(one, white, 0, s)
+    prev, first, mids = na, None, []
+    for i in range(1, n + 1):
+        if i & 1:
+            x = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Multiply if (i >> 1) & 1 else kc.MixType.Add)))
+            lg.connect(prev, x, 0, 0)
+            lg.connect(nb, x, 0, 1)
+        else:
+            x = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Subtract)))
+            lg.connect(white, x, 0, 0)
+            lg.connect(prev, x, 0, 1)
+        first = first if first is not None else x
+        mids.append(x)
+        prev = x
+    return tp, lg, na, nb, first, prev, mids
+
+
+def snapshot(lg):
+    ids = sorted(lg.node_ids())
+    return ([(i, lg.node_state(i)) for i in ids], [(i, len(lg.node_slot_datas(i))) for i in ids], sorted(lg.changed_consume()))
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (40, 130)])
+def test_replayed_evaluations_equal_the_walk_and_the_oracle(kc, orc, shape):
+    h, w = shape
+    a, b = synthetic_rgba(SEED_A, h, w), synthetic_rgba(SEED_B, h, w)
+    want = orc.chain32(a, b, 12)
+    kc.set_option("replay", 1)
+    tp1, lg1, na1, _, first1, last1, _ = chain_graph(kc, a, b, 12)
+    kc.set_option("replay", 0)
+    tp2, lg2, na2, _, first2, last2, _ = chain_graph(kc, a, b, 12)
+    n0 = kc.stats_counter("replayed_evaluations")
+    for rep in range(6):
+        kc.set_option("replay", 1)
+        lg1.connect(na1, first1, 0, 0)
+        got1 = lg1.await_clean(last1).slot_data(last1, 0).image.planes()
+        s1 = snapshot(lg1)
+        kc.set_option("replay", 0)
+        lg2.connect(na2, first2, 0, 0)
+        got2 = lg2.await_clean(last2).slot_data(last2, 0).image.planes()
+        s2 = snapshot(lg2)
+        assert_planes(got1, want, what="replay on, evaluation %d" % rep)
+        assert_planes(got2, want, what="replay off, evaluation %d" % rep)
+        assert s1 == s2, "evaluation %d: states / slot data / changed set differ between replay and walk" % rep
+    kc.set_option("replay", 1)
+    # the first evaluation builds everything, the second sees the steady-state starting point for the first time and is
+    # recorded, from the third on every one is a replay
+    assert kc.stats_counter("replayed_evaluations") - n0 >= 3
+
+
+def test_every_kind_of_edit_is_seen(kc, orc):
+    h, w = 48, 96
+    a, b, c = synthetic_rgba(SEED_A, h, w), synthetic_rgba(SEED_B, h, w), synthetic_rgba(SEED_A + 77, h, w)
+    kc.set_option("replay", 1)
+    tp, lg, na, nb, first, last, mids = chain_graph(kc, a, b, 6)
+
+    def run():
+        lg.connect(na, first, 0, 0)
+        return lg.await_clean(last).slot_data(last, 0).image.planes()
+
+    def settle():
+        n0 = kc.stats_counter("replayed_evaluations")
+        for _ in range(4):
+            got = run()
+        assert kc.stats_counter("replayed_evaluations") > n0, "the steady state should be replaying"
+        return got
+
+    def ref(a_, b_, ops, b_first=None):
+        x = a_[:3]
+        one = np.ones((h, w), np.float32)
+        for i, op in enumerate(ops, 1):
+            bb = b_first if (i == 1 and b_first is not None) else b_
+            x = [orc.mix_plane(op, x[ch], bb[ch]) for ch in range(3)] if i & 1 else [orc.mix_plane("Subtract", one, x[ch]) for ch in range(3)]
+        return x + [one]
+
+    ops = ["Add", "Subtract", "Multiply", "Subtract", "Add", "Subtract"]
+    assert_planes(settle(), ref(a, b, ops), what="baseline")
+    # 1. a Mix type changes
+    lg.set_mix_type(mids[2], kc.MixType.Divide)
+    ops[2] = "Divide"
+    assert_planes(run(), ref(a, b, ops), what="after set_mix_type")
+    assert_planes(settle(), ref(a, b, ops), what="after set_mix_type, replaying again")
+    # 2. another source: a third embedded image feeds the first Mix instead of B
+    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(c)), 2)
+    nc = lg.add_node(kc.Node.new(kc.NodeType.Embed(2)))
+    lg.connect(nc, first, 0, 1)
+    assert_planes(run(), ref(a, b, ops, b_first=c), what="after plugging another source")
+    assert_planes(settle(), ref(a, b, ops, b_first=c), what="another source, replaying again")
+    # 3. an edge moves: the first Mix reads C on both sides
+    lg.connect(nc, first, 0, 0)
+    got = lg.await_clean(last).slot_data(last, 0).image.planes()
+    assert_planes(got, ref(c, b, ops, b_first=c), what="after moving an edge")
+    lg.connect(na, first, 0, 0)
+    assert_planes(settle(), ref(a, b, ops, b_first=c), what="edge moved back")
+    # 4. use_cache on and off again
+    lg.use_cache = True
+    assert_planes(run(), ref(a, b, ops, b_first=c), what="use_cache on")
+    lg.use_cache = False
+    assert_planes(settle(), ref(a, b, ops, b_first=c), what="use_cache off again")
+    # 5. a node is appended and requested instead
+    tail = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)))
+    lg.connect(last, tail, 0, 0)
+    lg.connect(nb, tail, 0, 1)
+    got = lg.await_clean(tail).slot_data(tail, 0).image.planes()
+    want = ref(a, b, ops, b_first=c)
+    assert_planes(got, [orc.mix_plane("Add", want[ch], b[ch]) for ch in range(3)] + [np.ones((h, w), np.float32)], what="appended node")
+    # ... and the old request still works (the new node stays Dirty, the recording of `last` no longer matches: walk)
+    assert_planes(run(), want, what="old node after the append")
+    # 6. a Value changes: the invert constant becomes 0.5 (clamped by the implicit resize to [0, 1], still 0.5)
+    # (Value nodes are parameters of the graph: a new node with another value replaces the old one's edges)
+    half = lg.add_node(kc.Node.new(kc.NodeType.Value(0.5)))
+    white2 = lg.add_node(kc.Node.new(kc.NodeType.CombineRgba))
+    for s_ in range(3):
+        lg.connect(half, white2, 0, s_)
+    lg.connect(white2, mids[1], 0, 0)
+    got = run()
+    x = a[:3]
+    for i, op in enumerate(ops, 1):
+        bb = c if i == 1 else b
+        cst = np.full((h, w), 0.5 if i == 2 else 1.0, np.float32)
+        x = [orc.mix_plane(op, x[ch], bb[ch]) for ch in range(3)] if i & 1 else [orc.mix_plane("Subtract", cst, x[ch]) for ch in range(3)]
+    assert_planes(got, x + [np.ones((h, w), np.float32)], what="after changing a constant")
+
+
+def test_replay_off_switch_and_counter(kc):
+    h, w = 16, 32
+    a, b = synthetic_rgba(SEED_A, h, w), synthetic_rgba(SEED_B, h, w)
+    kc.set_option("replay", 0)
+    try:
+        tp, lg, na, nb, first, last, _ = chain_graph(kc, a, b, 4)
+        n0 = kc.stats_counter("replayed_evaluations")
+        for _ in range(5):
+            lg.connect(na, first, 0, 0)
+            lg.await_clean(last)
+        assert kc.stats_counter("replayed_evaluations") == n0
+        assert kc.get_option("replay") == 0
+    finally:
+        kc.set_option("replay", 1)
