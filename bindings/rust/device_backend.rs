@@ -34,10 +34,14 @@ impl Drop for DeviceImage {
 pub enum SlotImage { Gray(DeviceImage), Rgba(DeviceImage) }
 
 fn check(status: i32) -> Result<()> {
-    // 1..=19 are TexProError in declaration order (src/error.rs:5-27)
+    // 1..=19 are TexProError in declaration order (src/error.rs:5-27); the two variants that carry a payload are built
+    // from kc_last_error() (the library keeps the text, not the foreign error object); >= 100 are the library's own.
+    let text = || unsafe { CStr::from_ptr(kc_last_error()) }.to_string_lossy().into_owned();
     match status {
         0 => Ok(()),
+        1 => Err(TexProError::Generic),
         2 => Err(TexProError::Canceled),
+        3 => Err(TexProError::Image(image::ImageError::IoError(std::io::Error::new(std::io::ErrorKind::Other, text())))),
         4 => Err(TexProError::InvalidBufferCount),
         5 => Err(TexProError::InvalidNodeId),
         6 => Err(TexProError::InvalidNodeType),
@@ -45,10 +49,18 @@ fn check(status: i32) -> Result<()> {
         8 => Err(TexProError::InvalidSlotType),
         9 => Err(TexProError::InvalidEdge),
         10 => Err(TexProError::NoSlotData),
+        11 => Err(TexProError::SlotOccupied),
+        12 => Err(TexProError::SlotNotOccupied),
+        13 => Err(TexProError::UnableToLock),
         14 => Err(TexProError::NodeProcessing),
+        15 => Err(TexProError::PoisonError),
+        16 => Err(TexProError::TryLockError),
+        17 => Err(TexProError::NodeDirty),
+        18 => Err(TexProError::Io(std::io::Error::new(std::io::ErrorKind::Other, text()))),
+        19 => Err(TexProError::InvalidName),
         _ => {
-            let msg = unsafe { CStr::from_ptr(kc_last_error()) };
-            eprintln!("kanter_core_amd: status {}: {}", status, msg.to_string_lossy());
+            // KC_ERR_HIP / NO_DEVICE / INVALID_ARG / OUT_OF_MEMORY / UNSUPPORTED: no counterpart in the reference
+            eprintln!("kanter_core_amd: status {}: {}", status, text());
             Err(TexProError::Generic)
         }
     }

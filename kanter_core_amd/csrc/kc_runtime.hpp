@@ -170,6 +170,7 @@ struct TapsHost {
 };
 
 struct TapsEntry {
+    uint64_t last_use = 0;  // band tables only: LRU clock (Context::band_taps_clock)
     TapsHost host;
     void *dev_block = nullptr;
     size_t dev_bytes = 0;
@@ -190,6 +191,7 @@ struct ReplayCapture {
 struct Context {
     std::recursive_mutex mu;
     ReplayCapture *capture = nullptr;
+    uint64_t band_taps_clock = 0;
     bool inited = false;
     int device = -1;
     hipStream_t own_stream = nullptr;

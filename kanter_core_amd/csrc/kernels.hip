@@ -1504,10 +1504,14 @@ static __device__ __forceinline__ void h2n_quad(f4 px, f4 up, f4 left, float pdx
     const SharedDenominator4 d1 = sqrt_denominator4(q1), d2 = sqrt_denominator4(q2);
     const f4 tx = divide_by4<false>(d1, vdx), tz = divide_by4(d1, tz0);
     const f4 by = divide_by4<false>(d2, vdy), bz = divide_by4(d2, bz0);
-    const f4 ty = zero, bx = zero;  // 0 / n
-    const f4 cx = ty * bz - tz * by;
-    const f4 cy = tz * bx - tx * bz;
-    const f4 cz = tx * by - ty * bx;
+    // t = (tx, 0, tz), b = (0, by, bz): the cross product's products with the two zero components (0 / n = +0) vanish.
+    //   cx = 0 * bz - tz * by = -(tz * by),  cy = tz * 0 - tx * bz = -(tx * bz),  cz = tx * by - 0 * 0 = tx * by
+    // exactly, for the finite values of this path -- except the SIGN of a zero result (+-0 - +-0), which cannot reach the
+    // output: cx and cy enter as squares and as (+-0 / n) * 0.5 + 0.5 = 0.5.
+    (void)zero;
+    const f4 cx = -(tz * by);
+    const f4 cy = -(tx * bz);
+    const f4 cz = tx * by;
     const SharedDenominator4 d3 = sqrt_denominator4((cx * cx + cy * cy) + cz * cz);
     const f4 nx = divide_by4(d3, cx), ny = divide_by4(d3, cy), nz = divide_by4<false>(d3, cz);
     r = nx * half + half;
@@ -1597,10 +1601,12 @@ static __device__ __forceinline__ uint32_t quant_u8_srgb(float v, const uint32_t
     const uint32_t xb = __float_as_uint(x);  // non-negative floats order like their bit patterns
     if ((int32_t)xb <= 0) return 0u;         // +0.0, and -0.0 (which passes the clamp): srgb_to_linear returns s itself
     const float est = 255.0f * __builtin_amdgcn_exp2f(2.4f * __builtin_amdgcn_logf((x + 0.055f) * (1.0f / 1.055f)));
-    uint32_t q = xb < T[1] ? 0u : (uint32_t)fminf(est, 255.0f);
-    while (q < 255u && xb >= T[q + 1u]) ++q;
-    while (q > 0u && xb < T[q]) --q;
-    return q;
+    // The estimate is within one level of the answer for every float in [0, 1] (checked exhaustively on the device by
+    // profiles/srgb_exhaustive.py: all 1 065 353 217 of them through this kernel against the table's definition), so one
+    // comparison each way settles it: no data-dependent loop.  T[0] = 0 and the sentinel T[256] = 0xffffffff keep the
+    // look-ups inside the table at both ends.
+    const uint32_t q = xb < T[1] ? 0u : (uint32_t)fminf(est, 255.0f);
+    return q + (xb >= T[q + 1u] ? 1u : 0u) - (xb < T[q] ? 1u : 0u);
 }
 
 template <bool NT>
@@ -1615,9 +1621,10 @@ template <bool SRGB, bool NT>  // NT: the planes are read once and do not fit th
 __global__ __launch_bounds__(256) void to_u8_kernel(Operand r, Operand g, Operand b, Operand a, int gray, uint32_t w,
                                                     uint32_t h, uint8_t *__restrict__ dst)
 {
-    __shared__ uint32_t srgb_t[SRGB ? 256 : 1];
+    __shared__ uint32_t srgb_t[SRGB ? 257 : 1];
     if constexpr (SRGB) {
         srgb_t[threadIdx.x] = kSrgbThresholdBits[threadIdx.x];  // 256 threads
+        if (threadIdx.x == 0) srgb_t[256] = 0xffffffffu;         // sentinel: nothing is >= it
         __syncthreads();
     }
     const uint32_t *pow_tab = srgb_t;

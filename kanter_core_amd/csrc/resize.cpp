@@ -185,8 +185,10 @@ int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
     return KC_OK;
 }
 
-// Copies e.host into one device block and points e.dev at it.
-static int taps_upload(TapsEntry &e)
+// Copies e.host into one device block and points e.dev at it.  `pooled`: the block comes from the stream-ordered plane pool
+// (band tables, which are evicted while kernels that read them may still be queued: giving the block back to the pool is
+// safe in stream order and costs no device synchronisation, unlike hipFree); the pool's "in use" figure counts planes only.
+static int taps_upload(TapsEntry &e, bool pooled = false)
 {
     Context &c = ctx();
     const size_t nl = e.host.left.size() * sizeof(uint32_t);
@@ -197,7 +199,12 @@ static int taps_upload(TapsEntry &e)
     const size_t nu_pad = (nu + 255) / 256 * 256;
     const size_t nuq = e.host.up_ok ? e.host.up_qrows.size() * sizeof(float) : 0;
     e.dev_bytes = 2 * nl_pad + nw_pad + nu_pad + (nuq + 255) / 256 * 256;
-    KC_HIP(hipMalloc(&e.dev_block, e.dev_bytes));
+    if (pooled) {
+        KC_TRY(pool_alloc(e.dev_bytes, &e.dev_block));
+        c.bytes_in_use -= e.dev_bytes;
+    } else {
+        KC_HIP(hipMalloc(&e.dev_block, e.dev_bytes));
+    }
     char *base = (char *)e.dev_block;
     hipError_t err = hipMemcpyAsync(base, e.host.left.data(), nl, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess) err = hipMemcpyAsync(base + nl_pad, e.host.count.data(), nl, hipMemcpyHostToDevice, c.stream);
@@ -207,7 +214,12 @@ static int taps_upload(TapsEntry &e)
         err = hipMemcpyAsync(base + 2 * nl_pad + nw_pad + nu_pad, e.host.up_qrows.data(), nuq, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
     if (err != hipSuccess) {
-        (void)hipFree(e.dev_block);
+        if (pooled) {
+            c.bytes_in_use += e.dev_bytes;
+            pool_free(e.dev_block, e.dev_bytes);
+        } else {
+            (void)hipFree(e.dev_block);
+        }
         e.dev_block = nullptr;
         return hip_fail(err, "upload tap table");
     }
@@ -257,6 +269,7 @@ static int get_band_taps(uint32_t in_n, uint32_t out_n, int filter, int32_t a, i
             set_error("resize band: the source band does not hold the rows this output band needs (halo rows missing)");
             return KC_ERR_INVALID_ARG;
         }
+        it->second.last_use = ++c.band_taps_clock;
         *out = &it->second;
         return KC_OK;
     }
@@ -284,10 +297,20 @@ static int get_band_taps(uint32_t in_n, uint32_t out_n, int filter, int32_t a, i
         std::copy(full->host.w.begin() + (size_t)oy * stride, full->host.w.begin() + (size_t)(oy + 1) * stride,
                   e.host.w.begin() + (size_t)i * stride);
     }
-    KC_TRY(taps_upload(e));
-    if (c.band_taps.size() >= 64) {  // bands come in a handful of shapes per graph; bound what a long-lived process keeps
-        for (auto &kv : c.band_taps) (void)hipFree(kv.second.dev_block);
-        c.band_taps.clear();
+    KC_TRY(taps_upload(e, true));
+    // Bands come in a handful of shapes per graph; bound what a long-lived process keeps.  The least recently used table
+    // goes, ONE at a time, and its block returns to the stream-ordered pool: kernels already enqueued may still read it (whoever
+    // gets the block next is enqueued behind them), and a synchronous hipFree in the middle of an evaluation would stall the
+    // device (nobody holds a TapsEntry across a call that can get here: every caller launches right after its look-up,
+    // under the context lock).
+    e.last_use = ++c.band_taps_clock;
+    if (c.band_taps.size() >= 64) {
+        auto victim = c.band_taps.begin();
+        for (auto it = c.band_taps.begin(); it != c.band_taps.end(); ++it)
+            if (it->second.last_use < victim->second.last_use) victim = it;
+        c.bytes_in_use += victim->second.dev_bytes;
+        pool_free(victim->second.dev_block, victim->second.dev_bytes);
+        c.band_taps.erase(victim);
     }
     auto ins = c.band_taps.emplace(key, std::move(e));
     *out = &ins.first->second;
