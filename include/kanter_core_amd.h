@@ -404,7 +404,9 @@ KC_API int kc_live_graph_evaluate_partitioned(kc_live_graph *lg, const kc_partit
  * of their inputs; HeightToNormal one more row on top (toroidal: the band that starts at row 0 needs the LAST row,
  * src/node/process_shared.rs:31-65); an implicit resize the rows its vertical taps read (src/shared.rs:159-199).  The
  * evaluation widens every intermediate band by those halo rows and computes them redundantly: no exchange between ranks.
- * Graph and Write nodes are not supported here.
+ * Graph nodes (src/node/graph.rs:14-51) are expanded into their graphs before the walk (the resize the Graph node applies to
+ * its inputs becomes a SpecificSize pass-through in front of every inner Input node), nested ones too; Write nodes are
+ * not supported here.
  *   kc_live_graph_evaluate_band: `*out` (+1 ref) is an image of (y1 - y0) rows, resident on return.
  *   kc_live_graph_band_source_rows: which rows of every SOURCE (Embed / Image / Input*) that evaluation reads, so that
  *     sources which are themselves sharded by rows can be loaded with exactly their halo.  y0 may be negative: row -1 is

@@ -185,10 +185,11 @@ int target_size(Walk &W, const Node &n, const std::vector<kc_edge> &edges, kc_si
     return calculate_size(n.policy, sizes.data(), (int)sizes.size(), slot_index, n.policy_size, out);
 }
 
-int infer_sizes(Walk &W)
+int infer_sizes(Walk &W, const uint32_t *skip = nullptr)
 {
     const NodeGraph &g = W.lg.g;
     for (uint32_t id : W.topo) {
+        if (skip && id == *skip) continue;
         const Node &n = *g.find(id);
         kc_size s{ 1, 1 };
         bool rgba = false;
@@ -198,7 +199,7 @@ int infer_sizes(Walk &W)
         } else if (n.type == KC_NODE_VALUE) {
             s = kc_size{ 1, 1 };
         } else if (n.type == KC_NODE_GRAPH || n.type == KC_NODE_WRITE) {
-            set_error("row-band evaluation does not go through Graph / Write nodes");
+            set_error("row-band evaluation does not go through Write nodes (Graph nodes are expanded before the walk)");
             return KC_ERR_UNSUPPORTED;
         } else {
             const std::vector<kc_edge> &edges = g.edges_into(id);
@@ -555,6 +556,132 @@ int evaluate_node(Walk &W, const Node &n)
     return s;
 }
 
+// ---- Graph nodes ------------------------------------------------------------------------------------------
+// graph::process (src/node/graph.rs:14-51) evaluates a child graph on the Graph node's inputs -- which process_node has
+// resized to the node's target size T first (src/node/node_type.rs:229-237) -- and hands out the child's Output nodes as
+// the Graph node's output slots.  For the band walk the child graph is spliced into a copy of the parent graph:
+//   * every child node gets a fresh id, child edges keep their order;
+//   * a child InputGray(i) becomes a pass-through fed by the edge that enters the Graph node on slot i; a child InputRgba by
+//     the edge on the Graph node's lowest connected slot (input_rgba::process takes input_node_datas[0]).  The pass-through is
+//     an Output node whose resize policy is SpecificSize(T) with the Graph node's filter: exactly the resize the Graph node
+//     applied to that input (T computed here from the parents' inferred sizes by the Graph node's own policy);
+//   * an edge leaving the Graph node's slot o leaves the copy of the child's Output node o instead.
+// Nested Graph nodes come to the surface with their parent and are expanded in a later round.  The result holds no Graph
+// node among the root's ancestors; rows, halos and arithmetic are then what the walk below does for any other graph.
+int expand_graph_nodes(kc_live_graph &lg, uint32_t *root, uint32_t *slot, std::unique_ptr<kc_live_graph> &flat)
+{
+    auto has_graph_ancestor = [](const NodeGraph &g, uint32_t r, uint32_t *which) {
+        std::vector<uint32_t> topo;
+        if (topo_order(g, r, topo) != KC_OK) return false;
+        for (uint32_t id : topo)
+            if (g.find(id)->type == KC_NODE_GRAPH) {
+                *which = id;  // topological order: the first one has no Graph node above it
+                return true;
+            }
+        return false;
+    };
+    uint32_t gid = 0;
+    if (!has_graph_ancestor(lg.g, *root, &gid)) return KC_OK;
+    flat.reset(new kc_live_graph());
+    kc_live_graph &F = *flat;
+    F.tp = lg.tp;
+    F.base_dir = lg.base_dir;
+    F.depth = lg.depth;
+    F.g = lg.g;
+    for (auto &e : lg.embedded) {
+        image_retain(e.image);
+        F.embedded.push_back(e);
+    }
+    for (auto &i : lg.input_slot_datas) {
+        image_retain(i.image);
+        F.input_slot_datas.push_back(i);
+    }
+    for (int round = 0; has_graph_ancestor(F.g, *root, &gid); ++round) {
+        if (round > 64) {
+            set_error("Graph nodes nested too deeply");
+            return KC_ERR_NODE_PROCESSING;
+        }
+        const Node gn = *F.g.find(gid);
+        if (!gn.graph) {
+            set_error("Graph node without a graph");
+            return KC_ERR_NODE_PROCESSING;
+        }
+        // T: the Graph node's resize target, from the inferred sizes of its parents
+        Walk W(F);
+        KC_TRY(topo_order(F.g, gid, W.topo));
+        KC_TRY(infer_sizes(W, &gid));
+        const std::vector<kc_edge> in_edges = F.g.edges_into(gid);
+        kc_size T{ 1, 1 };
+        if (!in_edges.empty()) KC_TRY(target_size(W, gn, in_edges, &T));
+        const kc_edge *lowest = nullptr;
+        for (auto &e : in_edges)
+            if (!lowest || e.input_slot < lowest->input_slot) lowest = &e;
+        // copies of the child's nodes
+        const NodeGraph &cg = *gn.graph;
+        std::map<uint32_t, uint32_t> idmap;
+        std::vector<kc_edge> new_edges;
+        for (auto &cn : cg.nodes) {
+            Node c = cn;
+            c.node_id = F.g.new_id();
+            idmap[cn.node_id] = c.node_id;
+            if (cn.is_input()) {
+                const kc_edge *feed = nullptr;
+                if (cn.type == KC_NODE_INPUT_RGBA) feed = lowest;
+                else
+                    for (auto &e : in_edges)
+                        if (e.input_slot == cn.node_id) feed = &e;
+                if (!feed) {
+                    set_error("row band: an Input node of a Graph node's graph has nothing connected to it");
+                    return KC_ERR_NO_SLOT_DATA;
+                }
+                c.type = cn.type == KC_NODE_INPUT_RGBA ? KC_NODE_OUTPUT_RGBA : KC_NODE_OUTPUT_GRAY;
+                c.policy = KC_POLICY_SPECIFIC_SIZE;
+                c.policy_size = T;
+                c.filter = gn.filter;
+                c.graph.reset();
+                new_edges.push_back(kc_edge{ feed->output_id, c.node_id, feed->output_slot, 0 });
+            }
+            F.g.nodes.push_back(c);
+        }
+        // edges: those into the Graph node go (their pass-through copies were made above), those out of it are re-rooted in
+        // place (edge order is what the size policies see), the child's own follow
+        std::vector<kc_edge> edges;
+        for (auto &e : F.g.edges) {
+            if (e.input_id == gid) continue;
+            if (e.output_id == gid) {
+                auto it = idmap.find(e.output_slot);
+                if (it == idmap.end()) {
+                    set_error("row band: an edge leaves a Graph node on a slot its graph has no Output node for");
+                    return KC_ERR_INVALID_SLOT_ID;
+                }
+                edges.push_back(kc_edge{ it->second, e.input_id, 0, e.input_slot });
+            } else {
+                edges.push_back(e);
+            }
+        }
+        for (auto &e : new_edges) edges.push_back(e);
+        for (auto &e : cg.edges) edges.push_back(kc_edge{ idmap[e.output_id], idmap[e.input_id], e.output_slot, e.input_slot });
+        F.g.edges.swap(edges);
+        for (size_t i = 0; i < F.g.nodes.size(); ++i)
+            if (F.g.nodes[i].node_id == gid) {
+                F.g.nodes.erase(F.g.nodes.begin() + (long)i);
+                break;
+            }
+        F.g.touch();
+        if (*root == gid) {
+            auto it = idmap.find(*slot);
+            if (it == idmap.end()) {
+                set_error("the Graph node has no such output slot");
+                return KC_ERR_NO_SLOT_DATA;
+            }
+            *root = it->second;
+            *slot = 0;
+        }
+    }
+    F.reset_node_states();
+    return KC_OK;
+}
+
 int build_walk(Walk &W, uint32_t root, int32_t y0, int32_t y1)
 {
     if (!W.lg.g.find(root)) return KC_ERR_INVALID_NODE_ID;
@@ -565,8 +692,19 @@ int build_walk(Walk &W, uint32_t root, int32_t y0, int32_t y1)
 
 }  // namespace
 
-int band_source_rows(kc_live_graph &lg, uint32_t root, int32_t y0, int32_t y1, std::vector<kc_band_rows> &out)
+int band_source_rows(kc_live_graph &lg0, uint32_t root, int32_t y0, int32_t y1, std::vector<kc_band_rows> &out)
 {
+    if (!lg0.g.find(root)) return KC_ERR_INVALID_NODE_ID;
+    std::unique_ptr<kc_live_graph> flat;
+    uint32_t slot = 0;
+    if (lg0.g.find(root)->type == KC_NODE_GRAPH) {
+        // any output of the Graph node: the sources' rows are asked for per node, the first Output node stands for it
+        const std::vector<uint32_t> outs = lg0.g.find(root)->graph ? lg0.g.find(root)->graph->output_ids() : std::vector<uint32_t>{};
+        if (outs.empty()) return KC_ERR_NO_SLOT_DATA;
+        slot = outs[0];
+    }
+    KC_TRY(expand_graph_nodes(lg0, &root, &slot, flat));
+    kc_live_graph &lg = flat ? *flat : lg0;
     Walk W(lg);
     KC_TRY(build_walk(W, root, y0, y1));
     for (uint32_t id : W.topo) {
@@ -577,10 +715,14 @@ int band_source_rows(kc_live_graph &lg, uint32_t root, int32_t y0, int32_t y1, s
     return KC_OK;
 }
 
-int band_evaluate(kc_live_graph &lg, uint32_t root, uint32_t slot, int32_t y0, int32_t y1, kc_image **out)
+int band_evaluate(kc_live_graph &lg0, uint32_t root, uint32_t slot, int32_t y0, int32_t y1, kc_image **out)
 {
     *out = nullptr;
     KC_TRY(need_init());
+    if (!lg0.g.find(root)) return KC_ERR_INVALID_NODE_ID;
+    std::unique_ptr<kc_live_graph> flat;  // the graph with its Graph nodes expanded, if it has any above the root
+    KC_TRY(expand_graph_nodes(lg0, &root, &slot, flat));
+    kc_live_graph &lg = flat ? *flat : lg0;
     Walk W(lg);
     KC_TRY(build_walk(W, root, y0, y1));
     ResizeMemoScope memo;

@@ -201,3 +201,112 @@ def test_separate_of_a_gray_image_is_1x1_in_bands_too(kc):
     assert [p.shape for p in band] == [p.shape for p in whole] == [(1, 1)]
     assert_planes(band, whole, what="separate of gray")
     check_bands(kc, g.dict(), imgs, h2n, "separate of gray -> mix -> h2n")
+
+
+# ---- Graph nodes (src/node/graph.rs:14-51): expanded before the band walk (csrc/bands.cpp, expand_graph_nodes) ----
+def _inner_invert():
+    g = G()
+    white = g.add({"Value": 1.0})
+    inp = g.add({"InputGray": "in"})
+    sub = g.add({"Mix": "Subtract"})
+    out = g.add({"OutputGray": "out"})
+    g.connect(white, sub, 0, 0)
+    g.connect(inp, sub, 0, 1)
+    g.connect(sub, out, 0, 0)
+    return g.dict(), inp, out
+
+
+def test_bands_through_a_graph_node_config0_shape(kc):
+    """BASELINE config #0's shape -- Image -> SeparateRgba -> Graph(invert) -> OutputGray -- with the image embedded:
+    bands == whole image == oracle == 1 - R."""
+    from oracle import oracle as orc
+    inner, inp, outn = _inner_invert()
+    g = G()
+    src = g.add({"Embed": 0})
+    sep = g.add("SeparateRgba")
+    gn = g.add({"Graph": inner})
+    out = g.add({"OutputGray": "out"})
+    g.connect(src, sep, 0, 0)
+    g.connect(sep, gn, 0, inp)
+    g.connect(gn, out, outn, 0)
+    h, w = 37, 52
+    planes = [splitmix_plane(SEED_A, c, h, w) for c in range(4)]
+    whole = check_bands(kc, g.dict(), {0: planes}, out, "config #0 shape")
+    want = orc.RefGraph(g.dict(), embedded={0: orc.Image(planes)}).slot_data(out, 0).image.planes
+    assert_planes(whole, want, what="config #0 shape vs oracle")
+    assert_planes(whole, [np.float32(1.0) - planes[0]], what="closed form")
+    # the band of the Graph node itself, by its output slot
+    tp, lg = build(kc, g.dict(), {0: planes})
+    part = lg.evaluate_band(gn, 5, 20, slot_id=outn).planes()
+    assert_planes(part, [(np.float32(1.0) - planes[0])[5:20]], what="band of the Graph node's own slot")
+    rows = lg.band_source_rows(out, 5, 20)
+    assert rows == {src: (5, 20, w, h)}
+
+
+def test_bands_through_a_graph_node_that_resizes_its_inputs(kc):
+    """The Graph node's own resize (src/node/node_type.rs:229-237) happens before its graph sees the inputs: a 16 x 12 and a
+    64 x 48 input under MostPixels / CatmullRom, two Input nodes, a HeightToNormal inside (halo through the expansion)."""
+    from oracle import oracle as orc
+    ig = G()
+    ia = ig.add({"InputGray": "a"})
+    ib = ig.add({"InputGray": "b"})
+    mul = ig.add({"Mix": "Multiply"})
+    h2n = ig.add("HeightToNormal")
+    o1 = ig.add({"OutputRgba": "normal"})
+    o2 = ig.add({"OutputGray": "product"})
+    ig.connect(ia, mul, 0, 0)
+    ig.connect(ib, mul, 0, 1)
+    ig.connect(mul, h2n, 0, 0)
+    ig.connect(h2n, o1, 0, 0)
+    ig.connect(mul, o2, 0, 0)
+    g = G()
+    small, big = g.add({"Embed": 0}), g.add({"Embed": 1})
+    s1, s2 = g.add("SeparateRgba"), g.add("SeparateRgba")
+    gn = g.add({"Graph": ig.dict()}, filt="CatmullRom")
+    mix = g.add({"Mix": "Add"})
+    out = g.add({"OutputRgba": "out"})
+    g.connect(small, s1, 0, 0)
+    g.connect(big, s2, 0, 0)
+    g.connect(s1, gn, 1, ia)
+    g.connect(s2, gn, 2, ib)
+    g.connect(gn, mix, o1, 0)
+    g.connect(big, mix, 0, 1)
+    g.connect(mix, out, 0, 0)
+    a = [splitmix_plane(SEED_A, c, 12, 16) for c in range(4)]
+    b = [splitmix_plane(SEED_B, c, 48, 64) for c in range(4)]
+    whole = check_bands(kc, g.dict(), {0: a, 1: b}, out, "resizing Graph node")
+    want = orc.RefGraph(g.dict(), embedded={0: orc.Image(a), 1: orc.Image(b)}).slot_data(out, 0).image.planes
+    assert_planes(whole, want, what="resizing Graph node vs oracle")
+    # the second output of the same Graph node
+    tp, lg = build(kc, g.dict(), {0: a, 1: b})
+    full = lg.await_clean(gn).slot_data(gn, o2).image.planes()
+    tp2, lg2 = build(kc, g.dict(), {0: a, 1: b})
+    halves = [lg2.evaluate_band(gn, y0, y1, slot_id=o2).planes()[0] for (y0, y1) in ((0, 20), (20, 48))]
+    assert_planes([np.concatenate(halves, axis=0)], full, what="second output slot by bands")
+
+
+def test_bands_through_nested_graph_nodes(kc):
+    from oracle import oracle as orc
+    inner, inp, outn = _inner_invert()
+    mid = G()
+    m_in = mid.add({"InputGray": "x"})
+    m_g = mid.add({"Graph": inner})
+    m_mul = mid.add({"Mix": "Multiply"})
+    m_out = mid.add({"OutputGray": "y"})
+    mid.connect(m_in, m_g, 0, inp)
+    mid.connect(m_g, m_mul, outn, 0)
+    mid.connect(m_in, m_mul, 0, 1)
+    mid.connect(m_mul, m_out, 0, 0)
+    g = G()
+    src = g.add({"Embed": 0})
+    sep = g.add("SeparateRgba")
+    gn = g.add({"Graph": mid.dict()})
+    out = g.add({"OutputGray": "out"})
+    g.connect(src, sep, 0, 0)
+    g.connect(sep, gn, 2, m_in)
+    g.connect(gn, out, m_out, 0)
+    planes = [splitmix_plane(SEED_B, c, 29, 40) for c in range(4)]
+    whole = check_bands(kc, g.dict(), {0: planes}, out, "nested Graph nodes")
+    want = orc.RefGraph(g.dict(), embedded={0: orc.Image(planes)}).slot_data(out, 0).image.planes
+    assert_planes(whole, want, what="nested Graph nodes vs oracle")
+    assert_planes(whole, [(np.float32(1.0) - planes[2]) * planes[2]], what="closed form (1 - b) * b")
