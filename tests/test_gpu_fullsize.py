@@ -86,6 +86,34 @@ def test_config3_chain32_8192_crop_equivalence(kc, orc):
         assert_planes([p[y:y + 160, x:x + 192] for p in got], want, what="crop %d,%d" % (y, x))
 
 
+def test_config3_chain32_8192_by_row_bands_vs_oracle_crops(kc, orc):
+    """BASELINE config #3's actual multi-GPU shape: the 32-node graph at 8192x8192 split into two row bands, each evaluated
+    through the band path (kc_live_graph_evaluate_band) on a graph that holds only that band's rows of the inputs -- what
+    `bench.py --gpus 2` does on two GPUs, here one band after the other.  Three crops per band against the oracle."""
+    from bench import add_chain
+    from util import splitmix_rows
+    S = 8192
+    for (y0, y1) in ((0, S // 2), (S // 2, S)):
+        rows = y1 - y0
+        a = [splitmix_rows(SEED_A, c, S, S, y0, y1) for c in range(4)]
+        b = [splitmix_rows(SEED_B, c, S, S, y0, y1) for c in range(4)]
+        tp = kc.TextureProcessor.new()
+        lg = tp.new_live_graph()
+        lg.embed_slot_data_band(kc.SlotData(0, 0, kc.SlotImage.from_planes(a)), 0, y0, S)
+        lg.embed_slot_data_band(kc.SlotData(0, 0, kc.SlotImage.from_planes(b)), 1, y0, S)
+        na, nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(0))), lg.add_node(kc.Node.new(kc.NodeType.Embed(1)))
+        _, last = add_chain(kc, lg, na, nb, 32)
+        got = lg.evaluate_band(last, y0, y1).planes()
+        assert got[0].shape == (rows, S)
+        for r0 in (0, rows // 2 - 16, rows - 32):
+            for x0 in (0, S - 256):
+                ca = [p[r0:r0 + 32, x0:x0 + 256].copy() for p in a]
+                cb = [p[r0:r0 + 32, x0:x0 + 256].copy() for p in b]
+                want = orc.chain32(ca, cb, 32)
+                assert_planes([p[r0:r0 + 32, x0:x0 + 256] for p in got], want, what="band %d:%d crop %d,%d" % (y0, y1, r0, x0))
+        del got, lg, tp, a, b
+
+
 def test_config2_resize_512_to_4096_and_blend_chain_vs_oracle(kc, orc, planes4096):
     """BASELINE config #2: B 512^2 -> 4096^2 (Triangle, MostPixels) feeding a 3-node blend chain,
     through the LiveGraph so the implicit resize pre-step runs per consuming node."""
