@@ -65,3 +65,42 @@ def test_resize_kernels_fit_their_budgets(usage):
                  "resize_poly_kernelILi6ELi4EEE", "resize_poly_kernelILi6ELi8EEE", "resize_poly_kernelILi2ELi8EEE"):
         (u,) = find(usage, frag)
         assert u["VGPRs"] <= 128, (frag, u)
+
+
+def test_upsample_kernels_fit_their_budgets(usage):
+    # the plain integer-ratio up-sampling kernel (Triangle, wide tiles): 8 waves per SIMD
+    for frag in ("upsample_kernelILi3ELb1ELb0EEE", "upsample_kernelILi3ELb1ELb1EEE", "upsample_kernelILi1ELb1ELb0EEE"):
+        (u,) = find(usage, frag)
+        assert u["VGPRs"] <= 64, (frag, u)
+    for frag in ("upsample_kernelILi7ELb1ELb0EEE", "upsample_kernelILi5ELb0ELb0EEE"):
+        (u,) = find(usage, frag)
+        assert u["VGPRs"] <= 96, (frag, u)
+    # the interpreter-driven fused form (first sightings only): what resize_chain_kernel<2,3> needed 108 for
+    (u,) = find(usage, "upsample_chain_kernelILi2ELi3ELb1EEE")
+    assert u["VGPRs"] <= 96, u
+    for name, u in usage.items():
+        if "chain1_kernel" in name or "upsample" in name:
+            assert u.get("ScratchSize", 0) == 0, (name, u)
+
+
+def test_specialised_upsample_chain_kernel_keeps_full_occupancy(tmp_path):
+    """Config #2's program inside the up-sampling kernel, as the run-time specialiser emits it (generated source compiled
+    here with hipcc and the parity flags): <= 64 VGPRs = 8 waves per SIMD, no scratch.  (Round 2's resize_chain_kernel<2,3>:
+    108 VGPRs, 4 waves per SIMD.)"""
+    import kanter_core_amd as kc
+    from kanter_core_amd import build as kbuild
+    hipcc = kbuild._hipcc()
+    if shutil.which(hipcc) is None and not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    word = lambda code, src: code | ((src + 1) << 8)  # noqa: E731
+    src = kc.specialize_compile_check_upsample([word(0, 1), word(3, 0), word(1, 1)], n_in=2, start_src=0, taps=3, wide=True)
+    f = tmp_path / "upchain.hip"
+    f.write_text("#include <hip/hip_runtime.h>\n" + src)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+           "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", str(f), "-o", str(tmp_path / "upchain.o")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    vg = [int(x) for x in re.findall(r"remark:\s+VGPRs: (\d+)", r.stdout)]
+    sc = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stdout)]
+    assert vg and max(vg) <= 64, r.stdout[-2000:]
+    assert sc and max(sc) == 0
