@@ -256,8 +256,21 @@ int infer_sizes(Walk &W, const uint32_t *skip = nullptr)
 // source rows the vertical taps of output rows [a, b) read (a >= 0: no wrap)
 int resize_source_rows(uint32_t in_h, uint32_t out_h, int filter, int32_t a, int32_t b, int32_t *sa, int32_t *sb)
 {
-    TapsHost t;
-    KC_TRY(build_taps_host(in_h, out_h, filter, t));
+    // The planner asks this once per resize edge per call, and the stateless band path calls the planner every step: the
+    // windows (host only: no device needed here) are kept per (in, out, filter) instead of rebuilt -- O(image height) each.
+    // Callers hold the context lock.
+    static std::map<std::tuple<uint32_t, uint32_t, int>, std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> windows;
+    auto key = std::make_tuple(in_h, out_h, filter);
+    auto it = windows.find(key);
+    if (it == windows.end()) {
+        TapsHost th;
+        KC_TRY(build_taps_host(in_h, out_h, filter, th));
+        if (windows.size() >= 256) windows.clear();
+        it = windows.emplace(key, std::make_pair(std::move(th.left), std::move(th.count))).first;
+    }
+    struct {
+        const std::vector<uint32_t> &left, &count;
+    } t{ it->second.first, it->second.second };
     int64_t lo = in_h, hi = 0;
     for (int32_t y = a; y < b; ++y) {
         lo = std::min<int64_t>(lo, t.left[(size_t)y]);

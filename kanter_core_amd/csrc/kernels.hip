@@ -1431,48 +1431,84 @@ static __device__ __forceinline__ void h2n_px(float px, float up, float left, fl
 // v_pk_mul_f32: two pixels per instruction) -- this kernel is bound by vector-instruction issue, not by HBM.
 // Element by element these are exactly the operations of h2n_px's `tame` branch (same instructions, same order);
 // a quad with any pixel outside that range goes through h2n_px pixel by pixel.
-static __device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
-static __device__ __forceinline__ f4 rsq4(f4 x)
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <class V> static __device__ __forceinline__ V fmaV(V a, V b, V c) { return __builtin_elementwise_fma(a, b, c); }
+template <class V> static __device__ __forceinline__ V splatV(float v)
 {
-    return f4{ __builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y), __builtin_amdgcn_rsqf(x.z), __builtin_amdgcn_rsqf(x.w) };
+    V o;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(V) / sizeof(float)); ++i) o[i] = v;
+    return o;
 }
-static __device__ __forceinline__ f4 copysign4(f4 mag, f4 sgn)
+template <class V> static __device__ __forceinline__ V rsqV(V x)
 {
-    return f4{ __builtin_copysignf(mag.x, sgn.x), __builtin_copysignf(mag.y, sgn.y), __builtin_copysignf(mag.z, sgn.z),
-               __builtin_copysignf(mag.w, sgn.w) };
+    V o;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(V) / sizeof(float)); ++i) o[i] = __builtin_amdgcn_rsqf(x[i]);
+    return o;
 }
-struct SharedDenominator4 {
-    f4 nb, r;
+template <class V> static __device__ __forceinline__ V copysignV(V mag, V sgn)
+{
+    V o;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(V) / sizeof(float)); ++i) o[i] = __builtin_copysignf(mag[i], sgn[i]);
+    return o;
+}
+template <class V> struct SharedDenominatorV {
+    V nb, r;
 };
 // The denominator-only part of the division by n = sqrt_normal(x), with the reciprocal seeded by the rsq the square root
 // starts from anyway instead of a separate v_rcp_f32 of n: y = rsq(x) is 1 / n to ~2^-22, one Newton step on n takes it to
 // the same ~2^-45 the rcp-seeded step reaches, and the quotient's correction steps are the same.  Transcendental
 // instructions run at a quarter of the packed-math rate: this halves them (6 -> 3 per pixel).  Checked against a / sqrtf(x)
 // over 3 x 2^34 (a, x) pairs in the ranges h2n_quad establishes (profiles/exact_math_check.hip, r02_exact_math_check.txt).
-static __device__ __forceinline__ SharedDenominator4 sqrt_denominator4(f4 x)
+template <class V> static __device__ __forceinline__ SharedDenominatorV<V> sqrt_denominatorV(V x)
 {
-    const f4 half = { 0.5f, 0.5f, 0.5f, 0.5f }, one = { 1.0f, 1.0f, 1.0f, 1.0f };
-    const f4 y = rsq4(x);
-    const f4 s0 = x * y;
-    const f4 h0 = y * half;
-    const f4 e = fma4(-h0, s0, half);
-    const f4 h = fma4(h0, e, h0);
-    const f4 s = fma4(s0, e, s0);
-    const f4 d = fma4(-s, s, x);
-    const f4 n = fma4(d, h, s);  // sqrt_normal4(x)
-    const f4 er = fma4(-n, y, one);
-    return { -n, fma4(er, y, y) };
+    const V half = splatV<V>(0.5f), one = splatV<V>(1.0f);
+    const V y = rsqV(x);
+    const V s0 = x * y;
+    const V h0 = y * half;
+    const V e = fmaV(-h0, s0, half);
+    const V h = fmaV(h0, e, h0);
+    const V s = fmaV(s0, e, s0);
+    const V d = fmaV(-s, s, x);
+    const V n = fmaV(d, h, s);  // sqrt_normal(x)
+    const V er = fmaV(-n, y, one);
+    return { -n, fmaV(er, y, y) };
 }
 
-template <bool MAY_BE_ZERO = true>
-static __device__ __forceinline__ f4 divide_by4(const SharedDenominator4 &d, f4 a)
+template <bool MAY_BE_ZERO, class V>
+static __device__ __forceinline__ V divide_byV(const SharedDenominatorV<V> &d, V a)
 {
-    const f4 m = a * d.r;
-    const f4 f2 = fma4(d.nb, m, a);
-    const f4 f3 = fma4(f2, d.r, m);
-    const f4 f4_ = fma4(d.nb, f3, a);
-    const f4 q = fma4(f4_, d.r, f3);
-    return MAY_BE_ZERO ? copysign4(q, a) : q;
+    const V m = a * d.r;
+    const V f2_ = fmaV(d.nb, m, a);
+    const V f3 = fmaV(f2_, d.r, m);
+    const V f4_ = fmaV(d.nb, f3, a);
+    const V q = fmaV(f4_, d.r, f3);
+    return MAY_BE_ZERO ? copysignV(q, a) : q;
+}
+
+// The tame path on V = 2 or 4 pixels: element by element exactly the operations of h2n_px's `tame` branch.
+template <class V>
+static __device__ __forceinline__ void h2n_fast(V tz0, V bz0, float pdx, float pdy, V &r, V &g, V &b)
+{
+    const V vdx = splatV<V>(pdx), vdy = splatV<V>(pdy), half = splatV<V>(0.5f);
+    const V q1 = vdx * vdx + tz0 * tz0, q2 = vdy * vdy + bz0 * bz0;
+    const SharedDenominatorV<V> d1 = sqrt_denominatorV(q1), d2 = sqrt_denominatorV(q2);
+    const V tx = divide_byV<false>(d1, vdx), tz = divide_byV<true>(d1, tz0);
+    const V by = divide_byV<false>(d2, vdy), bz = divide_byV<true>(d2, bz0);
+    // t = (tx, 0, tz), b = (0, by, bz): the cross product's products with the two zero components (0 / n = +0) vanish.
+    //   cx = 0 * bz - tz * by = -(tz * by),  cy = tz * 0 - tx * bz = -(tx * bz),  cz = tx * by - 0 * 0 = tx * by
+    // exactly, for the finite values of this path -- except the SIGN of a zero result (+-0 - +-0), which cannot reach the
+    // output: cx and cy enter as squares and as (+-0 / n) * 0.5 + 0.5 = 0.5.
+    const V cx = -(tz * by);
+    const V cy = -(tx * bz);
+    const V cz = tx * by;
+    const SharedDenominatorV<V> d3 = sqrt_denominatorV((cx * cx + cy * cy) + cz * cz);
+    const V nx = divide_byV<true>(d3, cx), ny = divide_byV<true>(d3, cy), nz = divide_byV<false>(d3, cz);
+    r = nx * half + half;
+    g = ny * half + half;
+    b = nz * half + half;
 }
 
 static __device__ __forceinline__ bool tame1(float d)
@@ -1498,25 +1534,9 @@ static __device__ __forceinline__ void h2n_quad(f4 px, f4 up, f4 left, float pdx
         b = f4{ bb[0], bb[1], bb[2], bb[3] };
         return;
     }
-    const f4 vdx = { pdx, pdx, pdx, pdx }, vdy = { pdy, pdy, pdy, pdy }, half = { 0.5f, 0.5f, 0.5f, 0.5f };
-    const f4 zero = { 0.0f, 0.0f, 0.0f, 0.0f };
-    const f4 q1 = vdx * vdx + tz0 * tz0, q2 = vdy * vdy + bz0 * bz0;
-    const SharedDenominator4 d1 = sqrt_denominator4(q1), d2 = sqrt_denominator4(q2);
-    const f4 tx = divide_by4<false>(d1, vdx), tz = divide_by4(d1, tz0);
-    const f4 by = divide_by4<false>(d2, vdy), bz = divide_by4(d2, bz0);
-    // t = (tx, 0, tz), b = (0, by, bz): the cross product's products with the two zero components (0 / n = +0) vanish.
-    //   cx = 0 * bz - tz * by = -(tz * by),  cy = tz * 0 - tx * bz = -(tx * bz),  cz = tx * by - 0 * 0 = tx * by
-    // exactly, for the finite values of this path -- except the SIGN of a zero result (+-0 - +-0), which cannot reach the
-    // output: cx and cy enter as squares and as (+-0 / n) * 0.5 + 0.5 = 0.5.
-    (void)zero;
-    const f4 cx = -(tz * by);
-    const f4 cy = -(tx * bz);
-    const f4 cz = tx * by;
-    const SharedDenominator4 d3 = sqrt_denominator4((cx * cx + cy * cy) + cz * cz);
-    const f4 nx = divide_by4(d3, cx), ny = divide_by4(d3, cy), nz = divide_by4<false>(d3, cz);
-    r = nx * half + half;
-    g = ny * half + half;
-    b = nz * half + half;
+    // (as two pairs in sequence the fast path fits 62 VGPRs = 8 waves per SIMD, and is no faster: 50.1-50.5 against 51.3 us,
+    // profiles/r03_h2n_ab.txt -- the kernel is bound by vector issue and its hazard nops, not by occupancy)
+    h2n_fast<f4>(tz0, bz0, pdx, pdy, r, g, b);
 }
 
 // BAND = false: the whole plane, rows wrap around (row -1 = row h - 1).  BAND = true: a row band -- `hgt` holds
