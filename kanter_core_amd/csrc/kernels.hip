@@ -190,7 +190,10 @@ static __device__ __forceinline__ void chain_run(const ChainProgram &P, const ui
 // Fused Mix chain (src/node/mix.rs:136-192 applied N times without materialising the
 // intermediates).  K = distinct input planes, U = float4 per thread per decode, MODE = op set.
 // Algorithmic HBM bytes per pixel: 4 * (planes read + 1 written), whatever N is.
-template <int K, int U, int MODE>
+// NT: the launch's cache policy marks streams (ChainProgram::nt_mask != 0): every full-size input is read and the result stored
+// with the nontemporal hint.  (The interpreter runs a program's first two sightings only; it does not distinguish which input
+// the policy would have kept cacheable -- the kernels compiled for the program do.)
+template <int K, int U, int MODE, bool NT = false>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
 {
     __shared__ double pow_lds[MODE >= 2 ? KC_POW_TABLE_DOUBLES : 1];
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
             }
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                in[k][u] = idx < total ? inp[k][row * ipitch[k] + col] : f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                in[k][u] = idx < total ? ld_policy<NT>(&inp[k][row * ipitch[k] + col]) : f4{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
 
         chain_run<K, U, MODE>(P, b, in, acc, pow_tab);
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainProgram P)
                 row = idx / P.row_units;
                 col = idx - row * P.row_units;
             }
-            if (idx < total) outp[row * opitch + col] = acc[u];
+            if (idx < total) st_policy<NT>(&outp[row * opitch + col], acc[u]);
         }
     }
 }
@@ -282,6 +285,19 @@ __global__ __launch_bounds__(256) void chain_kernel_k0(const ChainProgram P)
 template <int U, int MODE>
 static hipError_t launch_chain_k(const ChainProgram &p, dim3 grid, hipStream_t s)
 {
+    // the nontemporal form exists for the default shapes only (U = 4 without pow, U = 1 with): tuning overrides stay plain
+    constexpr bool HAS_NT = (MODE < 2 && U == 4) || (MODE == 2 && U == 1);
+    if constexpr (HAS_NT) {
+        if (p.nt_mask != 0) {
+            switch (p.n_in) {
+            case 1: chain_kernel<1, U, MODE, true><<<grid, 256, 0, s>>>(p); return hipGetLastError();
+            case 2: chain_kernel<2, U, MODE, true><<<grid, 256, 0, s>>>(p); return hipGetLastError();
+            case 3: chain_kernel<3, U, MODE, true><<<grid, 256, 0, s>>>(p); return hipGetLastError();
+            case 4: chain_kernel<4, U, MODE, true><<<grid, 256, 0, s>>>(p); return hipGetLastError();
+            default: break;
+            }
+        }
+    }
     switch (p.n_in) {
     case 0: chain_kernel_k0<MODE><<<grid, 256, 0, s>>>(p); break;
     case 1: chain_kernel<1, U, MODE><<<grid, 256, 0, s>>>(p); break;
