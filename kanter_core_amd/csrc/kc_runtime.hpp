@@ -177,15 +177,21 @@ struct TapsEntry {
     TapsDev dev{};
 };
 
-// What chain_launch leaves behind while an evaluation is being recorded for replay (replay.cpp).
-struct ReplayCapture {
-    int n_launch = 0;
-    bool ok = true;
-    ChainProgram prog;
+// What chain_launch leaves behind while an evaluation is being recorded for replay (replay.cpp): one record per launch.
+struct ReplayLaunch {
+    ChainProgram prog;  // as launched: input and output pointers of the recorded run
     int batch = 0, mode = 0;
     uint32_t in_refs[KC_CHAIN_MAX_IN] = { 0, 0, 0, 0 };
     uint32_t w = 0, h = 0;
     kc_plane *planes[KC_CHAIN_MAX_BATCH] = { nullptr, nullptr, nullptr, nullptr };  // the lazy planes the launch made resident
+    // filled when the recording is closed: input (b, k) is output channel in_ch of recorded launch in_from (-1: a plane that
+    // existed before the evaluation and is held by the recording)
+    int in_from[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];
+    int in_ch[KC_CHAIN_MAX_BATCH][KC_CHAIN_MAX_IN];
+};
+struct ReplayCapture {
+    bool ok = true;
+    std::vector<ReplayLaunch> launches;
 };
 
 struct Context {

@@ -10,7 +10,9 @@
 //   * every node it processed is a Mix / Value / CombineRgba / SeparateRgba / Output / Embed node (an Embed node is processed
 //     again whenever its data has been dropped, src/engine.rs:58-75; what it yields is the embedded image, whose identity
 //     is part of the check below);
-//   * the device work was ONE plain chain launch, whose results are the requested node's planes (constants aside);
+//   * the device work was a sequence of plain chain launches (up to 32: config #4's eight branches and its add tree are nine),
+//     each reading planes that existed before the evaluation or results of earlier launches of the sequence, the last results
+//     being the requested node's planes (constants aside);
 //   * afterwards no processed node but the requested one holds slot data --
 // and the next await_clean of that node first checks whether the world looks exactly as it did before the recorded run:
 //   * the same graph, by content (every node's type and parameters, every edge, in order: hashed each time, no reliance on
@@ -18,9 +20,9 @@
 //   * the same state for every node;
 //   * the same slot data on the same nodes and the same embedded images, by image identity (the recording holds a reference on
 //     each, so an address cannot have been recycled); the requested node's own previous result is not an input and is ignored.
-// If so the walk is skipped: fresh result planes, the recorded program with the new output pointers through the same
-// dispatch as ever (chain_dispatch: ahead-of-time kernel / specialised kernel / interpreter, cache policy), then the recorded
-// bookkeeping -- states, dropped slot data, the changed set, the requested node's new slot.  Everything observable afterwards
+// If so the walk is skipped: fresh result planes for every launch, the recorded programs with the new output pointers (and the
+// new pointers of earlier results where a launch reads one) through the same dispatch as ever (chain_dispatch: ahead-of-time
+// kernel / specialised kernel / interpreter, cache policy), then the recorded bookkeeping -- states, dropped slot data, the changed set, the requested node's new slot.  Everything observable afterwards
 // is what the walk would have left; the planes hold the same bits because they come from the same program on the same inputs.
 // Anything else -- a different edge, a changed Mix type, another source image, a node that was Clean last time -- fails the
 // check and takes the walk, which records again.
@@ -41,13 +43,12 @@ struct kc_live_graph::ReplayEntry {
     std::vector<std::pair<uint32_t, int>> post_state;  // nodes whose state the run changed
     std::vector<uint32_t> dropped;                     // nodes whose slot data the run removed (the root included if it had any)
     std::vector<uint32_t> changed_ids;
-    ChainProgram prog;
-    int batch = 0, mode = 0;
-    uint32_t in_refs[KC_CHAIN_MAX_IN] = { 0, 0, 0, 0 };
-    uint32_t w = 0, h = 0;
+    std::vector<ReplayLaunch> launches;
+    uint32_t w = 0, h = 0;  // the requested node's image
     uint32_t root_slot = 0;
     int n_planes = 0;
-    int out_b[4] = { -1, -1, -1, -1 };  // >= 0: that channel of the launch; -1: a constant plane
+    int out_l[4] = { -1, -1, -1, -1 };  // >= 0: a result of that launch ...
+    int out_b[4] = { -1, -1, -1, -1 };  // ... channel out_b; out_l < 0: a constant plane
     float cval[4] = { 0, 0, 0, 0 };
 
     ~ReplayEntry()
@@ -131,38 +132,48 @@ int replay_try(kc_live_graph &lg, uint32_t id, bool *hit)
     }
     if (graph_content_hash(lg.g) != e->ghash) return KC_OK;
 
-    // ---- the launch ----
+    // ---- the launches ----
     Context &c = ctx();
-    ChainProgram P = e->prog;
-    kc_plane *outs[KC_CHAIN_MAX_BATCH] = { nullptr, nullptr, nullptr, nullptr };
+    std::vector<kc_plane *> outs(e->launches.size() * KC_CHAIN_MAX_BATCH, nullptr);  // [launch][channel]
     auto drop_outs = [&] {
         for (auto *o : outs) plane_release(o);
     };
-    for (int b = 0; b < e->batch; ++b) {
-        int s = plane_new_mem(e->w, e->h, &outs[b]);
-        if (s != KC_OK) {
-            drop_outs();
-            return s;
+    for (size_t li = 0; li < e->launches.size(); ++li) {
+        const ReplayLaunch &L = e->launches[li];
+        ChainProgram P = L.prog;
+        for (int b = 0; b < L.batch; ++b) {
+            kc_plane *&o = outs[li * KC_CHAIN_MAX_BATCH + b];
+            int s = plane_new_mem(L.w, L.h, &o);
+            if (s != KC_OK) {
+                drop_outs();
+                return s;
+            }
+            P.out[b] = o->dptr;
+            P.out_pitch[b] = (uint32_t)(o->pitch / 16);
+            for (uint32_t k = 0; k < P.n_in; ++k)
+                if (L.in_from[b][k] >= 0) {  // a result of an earlier launch of this replay
+                    const kc_plane *src = outs[(size_t)L.in_from[b][k] * KC_CHAIN_MAX_BATCH + L.in_ch[b][k]];
+                    P.in[b][k] = src->dptr;
+                    P.in_pitch[b][k] = (uint32_t)(src->pitch / 16);
+                }
         }
-        P.out[b] = outs[b]->dptr;
-        P.out_pitch[b] = (uint32_t)(outs[b]->pitch / 16);
+        const uint64_t px4 = 4ull * L.w * L.h;
+        P.nt_mask = chain_cache_policy(L.in_refs, P.n_in, px4 * L.batch, px4 * L.batch);
+        hipError_t he = chain_dispatch(P, L.batch, L.mode, L.w, L.h, outs[li * KC_CHAIN_MAX_BATCH]->pitch);
+        if (he != hipSuccess) {
+            drop_outs();
+            return hip_fail(he, "launch_chain (replay)");
+        }
+        c.launches++;
+        c.alg_bytes += (uint64_t)L.batch * px4 * (P.n_in + 1);
     }
-    const uint64_t px4 = 4ull * e->w * e->h;
-    P.nt_mask = chain_cache_policy(e->in_refs, P.n_in, px4 * e->batch, px4 * e->batch);
-    hipError_t he = chain_dispatch(P, e->batch, e->mode, e->w, e->h, outs[0]->pitch);
-    if (he != hipSuccess) {
-        drop_outs();
-        return hip_fail(he, "launch_chain (replay)");
-    }
-    c.launches++;
-    c.alg_bytes += (uint64_t)e->batch * px4 * (P.n_in + 1);
     c.counters["replayed_evaluations"]++;
 
     // ---- the result image ----
     kc_plane *planes[4] = { nullptr, nullptr, nullptr, nullptr };
     std::vector<kc_plane *> consts;
     for (int p = 0; p < e->n_planes; ++p) {
-        if (e->out_b[p] >= 0) planes[p] = outs[e->out_b[p]];
+        if (e->out_l[p] >= 0) planes[p] = outs[(size_t)e->out_l[p] * KC_CHAIN_MAX_BATCH + e->out_b[p]];
         else {
             planes[p] = plane_new_const(e->w, e->h, e->cval[p]);
             consts.push_back(planes[p]);
@@ -170,7 +181,7 @@ int replay_try(kc_live_graph &lg, uint32_t id, bool *hit)
     }
     kc_image *img = image_new(e->n_planes, planes);  // retains the planes
     for (auto *q : consts) plane_release(q);
-    drop_outs();
+    drop_outs();  // intermediates go back to the pool (stream order: the launches that read them are enqueued)
 
     // ---- the bookkeeping the walk would have done ----
     for (uint32_t d : e->dropped) lg.remove_nodes_data(d);
@@ -230,7 +241,7 @@ void replay_end(kc_live_graph &lg, uint32_t id, ReplayRecorder *r, int s)
     std::unique_ptr<ReplayRecorder> own(r);
     std::unique_ptr<kc_live_graph::ReplayEntry> e(r->entry);
     lg.replay_clear();
-    if (s != KC_OK || !r->cap.ok || r->cap.n_launch != 1 || c.launches - r->launches0 != 1) return;
+    if (s != KC_OK || !r->cap.ok || r->cap.launches.empty() || c.launches - r->launches0 != r->cap.launches.size()) return;
     // The nodes the run processed are those whose state it changed and, possibly, those that held no data before it (a
     // Clean parent whose data had been dropped is made Dirty, processed and dropped again: same state before and after).
     // All of them must be of a recordable type.
@@ -279,32 +290,48 @@ void replay_end(kc_live_graph &lg, uint32_t id, ReplayRecorder *r, int s)
     for (auto &h : e->pre_slots)
         if (!dropped.count(h.node) && !lg.find_slot(h.node, h.slot)) return;
     e->dropped.assign(dropped.begin(), dropped.end());
-    // the root's image: planes of this launch, or constants
+    // the root's image: results of the recorded launches, or constants
     const kc_image *img = root_sd->image;
-    const ReplayCapture &cap = r->cap;
-    if (img->w() != cap.w || img->h() != cap.h) return;
+    ReplayCapture &cap = r->cap;
+    e->w = img->w();
+    e->h = img->h();
     e->root_slot = root_sd->slot_id;
     e->n_planes = img->n;
     for (int p = 0; p < img->n; ++p) {
         const kc_plane *pl = img->planes[p];
-        e->out_b[p] = -1;
+        e->out_l[p] = e->out_b[p] = -1;
         if (pl->kind == kc_plane::CONST) {
             e->cval[p] = pl->cval;
             continue;
         }
-        for (int b = 0; b < cap.batch; ++b)
-            if (cap.planes[b] == pl) e->out_b[p] = b;
-        if (e->out_b[p] < 0) return;  // a plane from somewhere else (a pass-through of a source ...)
+        for (size_t li = 0; li < cap.launches.size(); ++li)
+            for (int b = 0; b < cap.launches[li].batch; ++b)
+                if (cap.launches[li].planes[b] == pl && cap.launches[li].w == img->w() && cap.launches[li].h == img->h()) {
+                    e->out_l[p] = (int)li;
+                    e->out_b[p] = b;
+                }
+        if (e->out_l[p] < 0) return;  // a plane from somewhere else (a pass-through of a source ...)
+    }
+    // which inputs are results of earlier launches of the sequence: by address, the LATEST earlier launch that wrote there
+    // (a pool block can be handed out twice during one evaluation; what a launch reads is what was written last)
+    for (size_t li = 0; li < cap.launches.size(); ++li) {
+        ReplayLaunch &L = cap.launches[li];
+        for (int b = 0; b < L.batch; ++b)
+            for (uint32_t k = 0; k < L.prog.n_in; ++k) {
+                L.in_from[b][k] = L.in_ch[b][k] = -1;
+                for (size_t lj = li; lj-- > 0 && L.in_from[b][k] < 0;)
+                    for (int bj = 0; bj < cap.launches[lj].batch; ++bj)
+                        if (cap.launches[lj].prog.out[bj] == L.prog.in[b][k]) {
+                            if (cap.launches[lj].w != L.w || cap.launches[lj].h != L.h) return;  // (cannot be: chains are pointwise)
+                            L.in_from[b][k] = (int)lj;
+                            L.in_ch[b][k] = bj;
+                        }
+            }
     }
     for (uint32_t ch : lg.changed)
         if (!r->changed0.count(ch)) e->changed_ids.push_back(ch);
     // ids already in the set before the run stay in it either way
-    e->prog = cap.prog;
-    e->batch = cap.batch;
-    e->mode = cap.mode;
-    std::memcpy(e->in_refs, cap.in_refs, sizeof e->in_refs);
-    e->w = cap.w;
-    e->h = cap.h;
+    e->launches = std::move(cap.launches);
     lg.replay = e.release();
 }
 

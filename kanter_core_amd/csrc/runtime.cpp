@@ -628,17 +628,18 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
     }
     if (c.capture) {  // an evaluation is being recorded for replay (replay.cpp)
         ReplayCapture &cap = *c.capture;
-        if (bc.sampled[0] || cap.n_launch >= 1) cap.ok = false;  // one plain chain launch is what a recording may hold
+        if (bc.sampled[0] || cap.launches.size() >= 32) cap.ok = false;  // plain chain launches are what a recording may hold
         else {
-            cap.prog = P;
-            cap.batch = batch;
-            cap.mode = bc.mode;
-            std::memcpy(cap.in_refs, bc.in_refs, sizeof cap.in_refs);
-            cap.w = p0->w;
-            cap.h = p0->h;
-            for (int b = 0; b < batch; ++b) cap.planes[b] = planes[b];
+            cap.launches.emplace_back();
+            ReplayLaunch &L = cap.launches.back();
+            L.prog = P;
+            L.batch = batch;
+            L.mode = bc.mode;
+            std::memcpy(L.in_refs, bc.in_refs, sizeof L.in_refs);
+            L.w = p0->w;
+            L.h = p0->h;
+            for (int b = 0; b < batch; ++b) L.planes[b] = planes[b];
         }
-        cap.n_launch++;
     }
     for (int b = 0; b < batch; ++b) {
         kc_plane *p = planes[b];

@@ -11,7 +11,7 @@ POINTERISH = (C.c_void_p, C.c_char_p)
 # and the mix / combine operators, whose NULL images mean "input not connected" (src/node/mix.rs:57-83)
 NULL_OK = {"kc_plane_release", "kc_image_release", "kc_node_graph_free", "kc_tex_pro_free", "kc_live_graph_free", "kc_partition_free",
            "kc_specialize_stats",  # every output is optional
-           "kc_set_stream", "kc_stats",  # kc_stats: every output is optional
+           "kc_set_stream", "kc_stats", "kc_comm_info", "kc_comm_stats",  # kc_stats, kc_comm_info / _stats: every output is optional
            "kc_resize_buffers"}  # n == 0: nothing to resize (src/shared.rs:147-149)
 
 

@@ -1,5 +1,5 @@
 """Replay of a recorded evaluation (csrc/replay.cpp): an await_clean that repeats the previous one of the same node exactly
-skips the node-by-node walk (the reference's src/engine.rs:200-307) and re-issues the recorded launch.  What must hold:
+skips the node-by-node walk (the reference's src/engine.rs:200-307) and re-issues the recorded launches.  What must hold:
   * replayed results are the oracle's, bit for bit, every time;
   * everything observable afterwards (node states, which nodes hold slot data, the changed set) is what the walk leaves;
   * any edit -- a Mix type, an edge, an embedded image, a value, use_cache, a new node -- is seen: the next evaluation walks."""
@@ -174,3 +174,110 @@ def test_replay_off_switch_and_counter(kc):
         assert kc.get_option("replay") == 0
     finally:
         kc.set_option("replay", 1)
+
+
+def fanin_live(kc, sources, sub_nodes):
+    """Config #4's shape: one BASELINE chain per (a, b) pair of `sources`, joined by a fixed-order Mix(Add) tree."""
+    tp = kc.TextureProcessor.new()
+    lg = tp.new_live_graph()
+    plugs, lasts = [], []
+    for k, (a, b) in enumerate(sources):
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(a)), 2 * k)
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(b)), 2 * k + 1)
+        na = lg.add_node(kc.Node.new(kc.NodeType.Embed(2 * k)))
+        nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(2 * k + 1)))
+        one = lg.add_node(kc.Node.new(kc.NodeType.Value(1.0)))
+        white = lg.add_node(kc.Node.new(kc.NodeType.CombineRgba))
+        for s in range(3):
+            lg.connect(one, white, 0, s)
+        prev, first = na, None
+        for i in range(1, sub_nodes + 1):
+            if i & 1:
+                x = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Multiply if (i >> 1) & 1 else kc.MixType.Add)))
+                lg.connect(prev, x, 0, 0)
+                lg.connect(nb, x, 0, 1)
+            else:
+                x = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Subtract)))
+                lg.connect(white, x, 0, 0)
+                lg.connect(prev, x, 0, 1)
+            first = first if first is not None else x
+            prev = x
+        plugs.append((na, first))
+        lasts.append(prev)
+    level = list(lasts)
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level) - 1, 2):
+            n = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)))
+            lg.connect(level[i], n, 0, 0)
+            lg.connect(level[i + 1], n, 0, 1)
+            nxt.append(n)
+        if len(level) & 1:
+            nxt.append(level[-1])
+        level = nxt
+    return tp, lg, plugs, level[0]
+
+
+def fanin_oracle(orc, sources, sub_nodes):
+    h, w = sources[0][0][0].shape
+    level = [orc.chain32(a, b, sub_nodes)[:3] for (a, b) in sources]
+    while len(level) > 1:
+        nxt = [[orc.mix_plane("Add", level[i][c], level[i + 1][c]) for c in range(3)] for i in range(0, len(level) - 1, 2)]
+        if len(level) & 1:
+            nxt.append(level[-1])
+        level = nxt
+    return level[0] + [np.ones((h, w), np.float32)]
+
+
+@pytest.mark.parametrize("n_branches,sub_nodes", [(8, 16), (5, 6), (2, 1)])
+def test_an_evaluation_of_several_launches_is_replayed(kc, orc, n_branches, sub_nodes):
+    """Config #4 on one device is nine launches (eight branches, then the add tree continuing from them): the recording
+    holds all of them, and which input of a later launch is which result of an earlier one."""
+    h, w = 24, 72
+    sources = [(synthetic_rgba(SEED_A + k, h, w), synthetic_rgba(SEED_B + k, h, w)) for k in range(n_branches)]
+    want = fanin_oracle(orc, sources, sub_nodes)
+    kc.set_option("replay", 1)
+    tp1, lg1, plugs1, root1 = fanin_live(kc, sources, sub_nodes)
+    kc.set_option("replay", 0)
+    tp2, lg2, plugs2, root2 = fanin_live(kc, sources, sub_nodes)
+    n0 = kc.stats_counter("replayed_evaluations")
+    launches = []
+    for rep in range(6):
+        kc.set_option("replay", 1)
+        for (na, first) in plugs1:
+            lg1.connect(na, first, 0, 0)
+        l0 = kc.stats()["kernel_launches"]
+        got1 = lg1.await_clean(root1).slot_data(root1, 0).image.planes()
+        launches.append(kc.stats()["kernel_launches"] - l0)
+        s1 = snapshot(lg1)
+        kc.set_option("replay", 0)
+        for (na, first) in plugs2:
+            lg2.connect(na, first, 0, 0)
+        got2 = lg2.await_clean(root2).slot_data(root2, 0).image.planes()
+        s2 = snapshot(lg2)
+        assert_planes(got1, want, what="replay on, evaluation %d" % rep)
+        assert_planes(got2, want, what="replay off, evaluation %d" % rep)
+        assert s1 == s2, "evaluation %d: states / slot data / changed set differ between replay and walk" % rep
+    kc.set_option("replay", 1)
+    assert kc.stats_counter("replayed_evaluations") - n0 >= 3
+    assert len(set(launches[1:])) == 1 and launches[1] >= 1, launches  # a replay issues the launches the walk issued
+    if n_branches > 1:
+        assert launches[1] > 1
+    # only SOME branches are re-plugged: another starting point, so the walk runs (and is recorded in its turn)
+    kc.set_option("replay", 1)
+    for rep in range(3):
+        lg1.connect(plugs1[0][0], plugs1[0][1], 0, 0)
+        got = lg1.await_clean(root1).slot_data(root1, 0).image.planes()
+        assert_planes(got, want, what="one branch re-plugged, evaluation %d" % rep)
+    # a source is replaced: the recording holds the old image and must not be used
+    c = synthetic_rgba(SEED_A + 991, h, w)
+    lg1.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(c)), 2 * n_branches)
+    nc = lg1.add_node(kc.Node.new(kc.NodeType.Embed(2 * n_branches)))
+    plugs1[0] = (nc, plugs1[0][1])
+    sources[0] = (c, sources[0][1])
+    want = fanin_oracle(orc, sources, sub_nodes)
+    for rep in range(4):
+        for (na, first) in plugs1:
+            lg1.connect(na, first, 0, 0)
+        got = lg1.await_clean(root1).slot_data(root1, 0).image.planes()
+        assert_planes(got, want, what="another source, evaluation %d" % rep)

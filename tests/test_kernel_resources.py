@@ -46,18 +46,19 @@ def find(usage, fragment):
 
 def test_no_kernel_spills_to_scratch(usage):
     for name, u in usage.items():
-        if "kc" in name and "ILi" in name and "Li2EEEv" in name and "chain_kernel" in name:
+        if "chain_kernel" in name and "ILi" in name and ("Li2EEEv" in name or "Li2ELb" in name):
             continue  # MODE 2 calls the f64 pow routine: a call frame is expected
         assert u.get("ScratchSize", 0) == 0, (name, u)
 
 
 def test_lean_chain_kernels_keep_full_occupancy(usage):
-    # chain_kernel<K, 4, 0>: K = 1, 2 must allow 8 waves per SIMD (<= 64 VGPRs)
-    for k in (1, 2):
-        (u,) = find(usage, "chain_kernelILi%dELi4ELi0EEE" % k)
-        assert u["VGPRs"] <= 64, (k, u)
-    (u,) = find(usage, "chain_kernelILi4ELi4ELi0EEE")
-    assert u["VGPRs"] <= 128, u
+    # chain_kernel<K, 4, 0, NT>: K = 1, 2 must allow 8 waves per SIMD (<= 64 VGPRs), with and without cache hints
+    for nt in (0, 1):
+        for k in (1, 2):
+            (u,) = find(usage, "chain_kernelILi%dELi4ELi0ELb%dEEE" % (k, nt))
+            assert u["VGPRs"] <= 64, (k, nt, u)
+        (u,) = find(usage, "chain_kernelILi4ELi4ELi0ELb%dEEE" % nt)
+        assert u["VGPRs"] <= 128, (nt, u)
 
 
 def test_resize_kernels_fit_their_budgets(usage):
