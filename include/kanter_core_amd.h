@@ -143,7 +143,9 @@ KC_API int kc_get_cache_policy(void);
  *   run-time specialiser, as longer programs do;
  *   "replay" 1 (default): an evaluation that repeats the previous one of the same node exactly (same graph by content, same
  *   node states, same slot data and embedded images by identity) skips the node-by-node walk of src/engine.rs:200-307 and
- *   re-issues the recorded launch; 0: always walk. */
+ *   re-issues the recorded launches; 0: always walk.
+ *   "down2" 0 / 1 (default) / 2: down-sampling with more than 8 taps on both axes runs resize_down2_kernel never / where the
+ *   integer-ratio streaming kernel does not apply / wherever its tables exist (bit-identical; A/B and tests). */
 KC_API int kc_set_option(const char *name, int value);
 KC_API int kc_get_option(const char *name, int *value);
 /* Diagnostics (host only, works without a device): the structure the integer-ratio up-sampling kernels rely on,
@@ -155,6 +157,16 @@ KC_API int kc_get_option(const char *name, int *value);
  * `rows` receives those (ratio + b_lo + b_hi) x taps weights (as many as fit `cap` floats). */
 KC_API int kc_resize_upsample_plan(uint32_t in_n, uint32_t out_n, int filter, int *eligible, int32_t info[5], float *rows,
                                    size_t cap);
+/* Diagnostics (host only): what resize_down2_kernel (csrc/down2.hip: down-sampling with more than 8 taps on both axes) reads for
+ * one axis of image::imageops::resize (src/shared.rs:159-199).  info = { stride (most taps of any output), nc, hstride, tile_w,
+ * fewest taps of any output }.  nc = records per group of four outputs when the table serves as the VERTICAL one (0: it cannot --
+ * at most 8 taps, or some group's windows span more than 64 source samples); hstride / tile_w = row pitch of the padded weights
+ * and strip width when it serves as the HORIZONTAL one (0: it cannot).  Optional outputs: left_count = out_n window starts then
+ * out_n tap counts, w = out_n x stride weights of the plain table, vrec = ceil(out_n / 4) x nc records of 72 dwords ([0] first
+ * source sample, [1], [2] presence mask of tap (sample u, output k) at bit 4 u + k, [3] last sample of the group's windows, [4]
+ * records in use, [8 + 4 u + k] weights), hw = out_n x hstride padded weights; each as many elements as its capacity allows. */
+KC_API int kc_resize_down2_plan(uint32_t in_n, uint32_t out_n, int filter, int32_t info[5], uint32_t *left_count, float *w, size_t wcap,
+                                uint32_t *vrec, size_t vcap, float *hw, size_t hcap);
 /* Pool statistics: bytes currently handed out, bytes cached for reuse, kernels launched. */
 KC_API int kc_stats(uint64_t *bytes_in_use, uint64_t *bytes_cached, uint64_t *kernel_launches);
 /* Algorithmic HBM bytes of every kernel launched so far: per launch, each resident input plane read once and each

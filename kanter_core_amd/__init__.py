@@ -10,7 +10,7 @@ from .api import (Edge, EmbeddedSlotDataId, LiveGraph, MixType, Node, NodeGraph,
                   init, is_initialized, mix_process, resize_image, separate_rgba_process, set_fusion, set_stream,
                   shutdown, stats, sync, value_process, set_specialize, get_specialize, specialize_wait,
                   specialize_stats, specialize_compile_check, Partition, PartitionPolicy, NodeKind, set_resize_mode,
-                  get_resize_mode, resize_upsample_plan, stats_counter, specialize_compile_check_upsample, set_cache_policy, get_cache_policy, set_option, get_option, comm_unique_id, comm_init,
+                  get_resize_mode, resize_upsample_plan, resize_down2_plan, stats_counter, specialize_compile_check_upsample, set_cache_policy, get_cache_policy, set_option, get_option, comm_unique_id, comm_init,
                   comm_destroy, comm_info, comm_stats)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

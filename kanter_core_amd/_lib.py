@@ -68,6 +68,8 @@ SIGNATURES = {
     "kc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "kc_get_cache_policy": (C.c_int, []),
     "kc_stats_counter": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64)]),
+    "kc_resize_down2_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                                       C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_float), C.c_size_t]),
     "kc_resize_upsample_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_float), C.c_size_t]),
     "kc_get_fusion": (C.c_int, []),

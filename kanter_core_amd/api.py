@@ -167,6 +167,29 @@ def resize_upsample_plan(in_n, out_n, filter=None):
     return dict(ratio=ratio, taps=taps, off=off, b_lo=b_lo, b_hi=b_hi, rows=rows)
 
 
+def resize_down2_plan(in_n, out_n, filter=None):
+    """Host only: the tables resize_down2_kernel reads for one axis (kc_resize_down2_plan), next to the plain tap table they
+    are built from: dict(stride, nc, hstride, tile_w, min_count, left, count, w[out_n, stride], vrec[groups, nc, 72] (uint32),
+    hw[out_n, hstride])."""
+    import numpy as np
+    L = _lib.load()
+    f = ResizeFilter.default() if filter is None else filter
+    info = (C.c_int32 * 5)()
+    _check(L.kc_resize_down2_plan(int(in_n), int(out_n), int(f), info, None, None, 0, None, 0, None, 0))
+    stride, nc, hstride, tile_w, min_count = (int(v) for v in info)
+    groups = (out_n + 3) // 4
+    lc = np.zeros(2 * out_n, np.uint32)
+    w = np.zeros((out_n, stride), np.float32)
+    vrec = np.zeros((groups, max(nc, 1), 72), np.uint32)
+    hw = np.zeros((out_n, max(hstride, 1)), np.float32)
+    _check(L.kc_resize_down2_plan(int(in_n), int(out_n), int(f), info, lc.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  w.ctypes.data_as(C.POINTER(C.c_float)), w.size,
+                                  vrec.ctypes.data_as(C.POINTER(C.c_uint32)), vrec.size if nc else 0,
+                                  hw.ctypes.data_as(C.POINTER(C.c_float)), hw.size if hstride else 0))
+    return dict(stride=stride, nc=nc, hstride=hstride, tile_w=tile_w, min_count=min_count, left=lc[:out_n].copy(),
+                count=lc[out_n:].copy(), w=w, vrec=vrec if nc else None, hw=hw if hstride else None)
+
+
 def set_specialize(mode, after=0):
     """Run-time specialisation of the fused chain kernel: 0 interpreter only, 1 compile in the background once a
     program has been seen `after` times (default), 2 compile at first sight and wait.  Bit-identical results."""

@@ -79,6 +79,7 @@ try {
     if (const char *rm = std::getenv("KC_RESIZE_MODE")) c.resize_mode = std::atoi(rm);
     if (const char *cp = std::getenv("KC_CACHE_POLICY")) c.cache_policy = std::atoi(cp) != 0;
     if (const char *c1 = std::getenv("KC_CHAIN1")) c.chain1 = std::atoi(c1) != 0;
+    if (const char *d2 = std::getenv("KC_DOWN2")) c.down2 = std::max(0, std::min(2, std::atoi(d2)));
     if (const char *rt = std::getenv("KC_RESIZE_TILE_H")) c.resize_tile_h = std::atoi(rt);
     if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
     if (const char *cu = std::getenv("KC_CHAIN_UNROLL")) {
@@ -232,6 +233,7 @@ try {
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
     if (std::strcmp(name, "chain1") == 0) ctx().chain1 = value != 0;
     else if (std::strcmp(name, "replay") == 0) ctx().replay = value != 0;
+    else if (std::strcmp(name, "down2") == 0 && value >= 0 && value <= 2) ctx().down2 = value;
     else {
         set_error(std::string("unknown option ") + name);
         return KC_ERR_INVALID_ARG;
@@ -245,6 +247,7 @@ try {
     KC_ARG(name && value);
     if (std::strcmp(name, "chain1") == 0) *value = ctx().chain1 ? 1 : 0;
     else if (std::strcmp(name, "replay") == 0) *value = ctx().replay ? 1 : 0;
+    else if (std::strcmp(name, "down2") == 0) *value = ctx().down2;
     else {
         set_error(std::string("unknown option ") + name);
         return KC_ERR_INVALID_ARG;
@@ -267,6 +270,32 @@ try {
     info[4] = (int32_t)t.up.b_hi;
     if (rows)
         for (size_t i = 0; i < t.up_rows.size() && i < cap; ++i) rows[i] = t.up_rows[i];
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_resize_down2_plan(uint32_t in_n, uint32_t out_n, int filter, int32_t info[5], uint32_t *left_count, float *w, size_t wcap,
+                         uint32_t *vrec, size_t vcap, float *hw, size_t hcap)
+try {
+    KC_ARG(info);
+    TapsHost t;
+    KC_TRY(build_taps_host(in_n, out_n, filter, t));
+    info[0] = (int32_t)t.stride;
+    info[1] = (int32_t)t.d2_nc;
+    info[2] = (int32_t)t.d2_hstride;
+    info[3] = (int32_t)t.d2_tile_w;
+    info[4] = (int32_t)t.min_count;
+    if (left_count)
+        for (uint32_t o = 0; o < out_n; ++o) {
+            left_count[o] = t.left[o];
+            left_count[out_n + o] = t.count[o];
+        }
+    if (w)
+        for (size_t i = 0; i < t.w.size() && i < wcap; ++i) w[i] = t.w[i];
+    if (vrec)
+        for (size_t i = 0; i < t.d2_vrec.size() && i < vcap; ++i) vrec[i] = t.d2_vrec[i];
+    if (hw)
+        for (size_t i = 0; i < t.d2_hw.size() && i < hcap; ++i) hw[i] = t.d2_hw[i];
     return KC_OK;
 }
 KC_CATCH

@@ -1,0 +1,232 @@
+// Down-sampling on both axes (more than 8 taps each way; image::imageops::resize of crate image 0.24.0 as called from
+// src/shared.rs:159-199), third form: every WAVE is a job of its own -- no workgroup barrier, no staging shared between waves.
+//
+// What bounded resize_down_kernel (profiles/r03_down_lds_experiment.txt) was not traffic but a wave's chain of dependent
+// waits: four trips of loads, and inside every trip scalar weight loads whose addresses depend on window tests (up to 48
+// load -> wait -> use round trips per wave), on 25 of 64 lanes, at 3-4 workgroups per CU.  Here:
+//   vertical pass    a wave owns 4 adjacent output rows and 64 source column quads.  The host lays the rows' weights out
+//                    DENSELY per source row (resize.cpp, down2_build): record (group, chunk) = first source row, a 64-bit
+//                    presence mask and w[16 source rows][4 output rows].  The wave fetches the record with scalar loads at
+//                    addresses that depend on nothing but its row group, issues its 16 row loads unconditionally (clamped
+//                    to the group's last window row) and then runs straight through: tap (u, k) is one scalar bit test
+//                    around two packed multiplies and two packed adds.  Absent taps are skipped, not multiplied by zero:
+//                    the sums receive exactly the reference's terms in the reference's order.
+//   transposition    the four sums of a column go to the wave's own 4 KB of LDS as ONE 16-byte entry (rows 0-3 of that
+//                    column), so that
+//   horizontal pass  a lane owns an output column (HC of them, 64 apart) for all four rows: one ds_read_b128 per tap feeds
+//                    four sums; its weights sit in registers, loaded as 16-byte quads from a copy of the horizontal table
+//                    whose rows are padded to a multiple of four.  Taps past a column's own count are replaced by -0.0,
+//                    which leaves every sum unchanged (as in resize_down_hrows).
+// A strip is as wide as 64 source quads allow (178 columns for Lanczos3 at 4096 -> 3000): every lane of the vertical pass
+// has a quad, and 16.5 KB of LDS per workgroup carry 2 848 results instead of 1 024.
+#include "kc_internal.hpp"
+
+namespace kc {
+namespace {
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float d2_clamp(float t)
+{
+    // image::math::utils::clamp: NaN compares false both ways and passes through.
+    if (t < 0.0f) return 0.0f;
+    if (t > 1.0f) return 1.0f;
+    return t;
+}
+
+typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+typedef const u16v __attribute__((address_space(4))) *d2_const_u16v;
+typedef const uint32_t __attribute__((address_space(4))) *d2_const_u32;
+__device__ __forceinline__ d2_const_u32 d2_const(const uint32_t *p)
+{
+    return (d2_const_u32)(uintptr_t)p;  // kernel-lifetime constants: scalar loads
+}
+}  // namespace
+
+template <int HC, int NW4, bool EARLY_W>
+__global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P, const Down2Args A)
+{
+    __shared__ f4 T[4][KC_DOWN2_SLOTS];  // wave-private: T[wave][source column of the strip] = (row 0, 1, 2, 3)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    const uint32_t g = blockIdx.y * 4u + wave;  // row group: output rows 4 g .. 4 g + 3
+    if (4u * g >= A.dh) return;                 // (no barrier anywhere in this kernel)
+    const uint32_t x0 = blockIdx.x * A.tile_w, x1 = min(x0 + A.tile_w, A.dw);
+    const d2_const_u32 hl = d2_const(A.hleft), hn = d2_const(A.hcount);
+    const uint32_t c0 = hl[x0] & ~3u;
+    const uint32_t nq = (hl[x1 - 1u] + hn[x1 - 1u] - c0 + 3u) / 4u;  // <= 64 (host-checked)
+    const uint32_t z = blockIdx.z;
+    const uint32_t sp4 = P.spitch[z] / 4u;
+    const f4 *col = reinterpret_cast<const f4 *>(P.src[z] + c0) + min(lane, nq - 1u);
+
+    // ---- this lane's output columns: window start, tap count, weights ----
+    uint32_t h0[HC], n[HC];
+    const f4 *wrow[HC];
+    f4 w[HC][NW4];
+#pragma unroll
+    for (int c = 0; c < HC; ++c) {
+        const uint32_t x = min(x0 + lane + 64u * c, x1 - 1u);
+        h0[c] = A.hleft[x] - c0;
+        n[c] = A.hcount[x];
+        wrow[c] = reinterpret_cast<const f4 *>(A.hw + (size_t)x * A.hstride);
+    }
+
+    // the slots past the 256 a wave fills are read by the last columns' padded taps: zero weights, so any finite value will do
+    if (lane < KC_DOWN2_SLOTS - 256u) T[wave][256u + lane] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+    // ---- vertical pass ----
+    const d2_const_u32 rec0 = d2_const(A.vrec) + (size_t)g * A.nc * KC_DOWN2_REC;
+    const uint32_t nch = rec0[4];
+    f2 alo[4], ahi[4];  // sums of the quad's columns 0, 1 and 2, 3 for the four rows (pairs: one packed operation each)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) alo[k] = ahi[k] = f2{ 0.0f, 0.0f };
+    for (uint32_t ch = 0; ch < nch; ++ch) {
+        const d2_const_u32 r = rec0 + ch * KC_DOWN2_REC;
+        const uint32_t s0 = r[0], last = r[3];
+        const uint64_t mask = (uint64_t)r[1] | ((uint64_t)r[2] << 32);  // bit 4 u + k: output row k has a tap on source row s0 + u
+        f4 p[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) p[u] = col[(size_t)min(s0 + (uint32_t)u, last) * sp4];
+        // the chunk's 64 weights: four scalar loads in flight behind the row loads (left to itself the compiler fetches them
+        // one after the other into the same registers, each with a wait of its own, between the arithmetic)
+        u16v W[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) W[i] = *reinterpret_cast<d2_const_u16v>(r + 8 + 16 * i);
+        asm volatile("" ::"s"(W[0]), "s"(W[1]), "s"(W[2]), "s"(W[3]));
+        if (EARLY_W && ch == 0u) {
+#pragma unroll
+            for (int c = 0; c < HC; ++c)
+#pragma unroll
+                for (int i = 0; i < NW4; ++i) w[c][i] = wrow[c][i];
+        }
+        // A tap that output row k does not have carries the weight +0.0 in the record.  Its product is +-0 and adding that
+        // to a sum that started at +0.0 never changes it (such a sum is never -0.0) -- as long as the sample is finite.
+        // One test per chunk finds the waves for which that fails; they take the exact form below.
+        float big = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            big = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_fabsf(p[u].x), __builtin_fabsf(p[u].y)), big);
+            big = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_fabsf(p[u].z), __builtin_fabsf(p[u].w)), big);
+        }
+        if (__builtin_amdgcn_ballot_w64(!(big < __builtin_inff())) == 0ull) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t wbits = W[u >> 2][4 * (u & 3) + k];  // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
+                    const float wt = __builtin_bit_cast(float, wbits);
+                    alo[k] += f2{ p[u].x, p[u].y } * wt;
+                    ahi[k] += f2{ p[u].z, p[u].w } * wt;
+                }
+        } else {
+            // some sample of the chunk is infinite or NaN: absent taps are left out by a per-lane select (the mask is the
+            // same in every lane; as a vector value it keeps this arm free of branches)
+            uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+            asm volatile("" : "+v"(mlo), "+v"(mhi));
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t wbits = W[u >> 2][4 * (u & 3) + k];  // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
+                    const float wt = __builtin_bit_cast(float, wbits);
+                    const int bit = 4 * u + k;
+                    const bool on = ((bit < 32 ? mlo >> bit : mhi >> (bit - 32)) & 1u) != 0u;
+                    const f2 tlo = f2{ p[u].x, p[u].y } * wt, thi = f2{ p[u].z, p[u].w } * wt;
+                    alo[k] += on ? tlo : f2{ 0.0f, 0.0f };
+                    ahi[k] += on ? thi : f2{ 0.0f, 0.0f };
+                }
+        }
+    }
+    if (!EARLY_W) {
+#pragma unroll
+        for (int c = 0; c < HC; ++c)
+#pragma unroll
+            for (int i = 0; i < NW4; ++i) w[c][i] = wrow[c][i];
+    }
+
+    // ---- transposition through the wave's own LDS ----
+    f4 *Tw = T[wave];
+    float big = 0.0f;  // the horizontal pass pads its windows with zero weights too: are the intermediate values finite?
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        big = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_fabsf(alo[k].x), __builtin_fabsf(alo[k].y)), big);
+        big = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_fabsf(ahi[k].x), __builtin_fabsf(ahi[k].y)), big);
+    }
+    const bool finite = __builtin_amdgcn_ballot_w64(!(big < __builtin_inff())) == 0ull;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        Tw[4u * lane + c] = f4{ alo[0][c], alo[1][c], alo[2][c], alo[3][c] };
+        Tw[4u * lane + 2 + c] = f4{ ahi[0][c], ahi[1][c], ahi[2][c], ahi[3][c] };
+    }
+    // the slots are this wave's own: its lanes' writes only have to be ordered before its lanes' reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- horizontal pass ----
+    float *dst = P.dst[z] + (size_t)(4u * g) * P.dpitch[z];
+    const uint32_t rows = min(4u, A.dh - 4u * g);
+    f4 sum[HC];
+    if (finite) {
+        // Every lane runs all 4 NW4 taps: the table's rows are padded with +0.0 weights, and +-0 added to a sum that began at
+        // +0.0 leaves it as it is.
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+            const f4 *t = Tw + h0[c];
+            sum[c] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int j = 0; j < 4 * NW4; ++j) sum[c] += t[j] * w[c][j >> 2][j & 3];
+        }
+    } else {
+        // an infinite or NaN intermediate value somewhere in the wave's rows: taps a column does not have are left out
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+            const f4 *t = Tw + h0[c];
+            sum[c] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int j = 0; j < 4 * NW4; ++j) {
+                const f4 term = t[j] * w[c][j >> 2][j & 3];
+                sum[c] += (uint32_t)j < n[c] ? term : f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < HC; ++c) {
+        const uint32_t x = x0 + lane + 64u * c;
+        if (x < x1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((uint32_t)k < rows) dst[(size_t)k * P.dpitch[z] + x] = d2_clamp(sum[c][k]);
+        }
+    }
+}
+
+hipError_t launch_resize_down2(const ResizePlanes &p, int batch, const Down2Args &a, hipStream_t s)
+{
+    if (a.dw == 0 || a.dh == 0) return hipSuccess;
+    if (batch < 1 || batch > 4) return hipErrorInvalidValue;
+    const uint32_t nw4 = a.hstride / 4u;
+    if (a.hstride % 4u != 0 || nw4 < 3 || nw4 > 8 || a.nc < 1 || a.nc > KC_DOWN2_MAX_CHUNKS || a.tile_w == 0 || a.hmax > a.hstride ||
+        a.hmin > a.hmax)
+        return hipErrorInvalidValue;
+    const uint32_t hc = down2_cols_per_lane(nw4);
+    if (a.tile_w > 64u * hc) return hipErrorInvalidValue;
+    dim3 grid((a.dw + a.tile_w - 1) / a.tile_w, (a.dh + 15u) / 16u, batch);
+    static const bool early = !(std::getenv("KC_DOWN2_LATE_W") && std::atoi(std::getenv("KC_DOWN2_LATE_W")) != 0);
+#define KC_D2(HC, NW4)                                                        \
+    do {                                                                      \
+        if (early) resize_down2_kernel<HC, NW4, true><<<grid, 256, 0, s>>>(p, a);  \
+        else resize_down2_kernel<HC, NW4, false><<<grid, 256, 0, s>>>(p, a);       \
+    } while (0)
+    switch (nw4) {
+    case 3: KC_D2(3, 3); break;
+    case 4: KC_D2(2, 4); break;
+    case 5: KC_D2(1, 5); break;
+    case 6: KC_D2(1, 6); break;
+    case 7: KC_D2(1, 7); break;
+    default: KC_D2(1, 8); break;
+    }
+#undef KC_D2
+    return hipGetLastError();
+}
+
+}  // namespace kc

@@ -82,6 +82,22 @@ struct ResizePlanes {
     float *dst[4];
     uint32_t spitch[4], dpitch[4];  // in floats
 };
+// resize_down2_kernel (down2.hip): the wave-private form of down-sampling on both axes.
+//   vrec     per group of 4 output rows `nc` records of KC_DOWN2_REC dwords: [0] first source row of the chunk, [1], [2] presence
+//            mask of tap (source row u, output row k) at bit 4 u + k, [3] the group's last window row (loads are clamped to
+//            it), [4] chunks this group uses, [8 + 4 u + k] the weight (resize.cpp, down2_build)
+//   hw       the horizontal table's weights, rows padded to hstride (a multiple of 4) floats
+constexpr uint32_t KC_DOWN2_REC = 72, KC_DOWN2_MAX_CHUNKS = 4, KC_DOWN2_SLOTS = 256 + 32;
+struct Down2Args {
+    const uint32_t *vrec;
+    const uint32_t *hleft, *hcount;
+    const float *hw;
+    uint32_t nc, hstride, hmin, hmax;  // hmin / hmax: fewest / most taps of any output column
+    uint32_t tile_w, dw, dh;
+};
+// output columns per lane of the horizontal pass: its weights live in registers (at most 9 quads per lane)
+inline uint32_t down2_cols_per_lane(uint32_t weight_quads) { return weight_quads <= 3 ? 3u : weight_quads == 4 ? 2u : 1u; }
+hipError_t launch_resize_down2(const ResizePlanes &p, int batch, const Down2Args &a, hipStream_t s);
 hipError_t launch_resize_lds(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
                              uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);
 hipError_t launch_resize_down(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,

@@ -106,6 +106,90 @@ static void up_axis_build(uint32_t in_n, uint32_t out_n, TapsHost &t)
     t.up_ok = true;
 }
 
+// The widest source-column window any tile_w-wide output tile needs, measured from its first column
+// rounded down to a multiple of 4, in whole 4-column groups.
+static uint32_t tile_groups(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
+{
+    uint32_t groups = 1;
+    for (uint32_t x0 = 0; x0 < out_n; x0 += tile_w) {
+        const uint32_t x1 = std::min(out_n, x0 + tile_w);
+        const uint32_t n = (h.left[x1 - 1] + h.count[x1 - 1] - (h.left[x0] & ~3u) + 3u) / 4u;
+        if (n > groups) groups = n;
+    }
+    return groups;
+}
+
+// What resize_down2_kernel (down2.hip) reads instead of the plain table, for tables of more than KC_RESIZE_REG_TAPS taps.
+// Vertical use: per group of four output rows the union of their windows in chunks of 16 source rows; record (group, chunk)
+// holds the weight of tap (source row u of the chunk, output row k of the group) at [8 + 4 u + k] -- +0.0 and a clear mask
+// bit where row k has no tap on that source row -- so the kernel needs no per-tap look-up.  The weights are the table's own
+// f32 values; ascending u is ascending tap index for every row, so the sums run in the reference's order.
+// Horizontal use: rows padded to a multiple of four weights, and the strip width.
+void down2_build(uint32_t out_n, TapsHost &t)
+{
+    t.d2_nc = t.d2_hstride = t.d2_tile_w = 0;
+    t.d2_vrec.clear();
+    t.d2_hw.clear();
+    if (t.stride <= KC_RESIZE_REG_TAPS || out_n == 0) return;
+    const uint32_t groups = (out_n + 3u) / 4u;
+    uint32_t nc = 0;
+    for (uint32_t g = 0; g < groups; ++g) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        for (uint32_t y = 4u * g; y < std::min(out_n, 4u * g + 4u); ++y) {
+            lo = std::min(lo, t.left[y]);
+            hi = std::max(hi, t.left[y] + t.count[y]);
+        }
+        nc = std::max(nc, (hi - lo + 15u) / 16u);
+    }
+    if (nc >= 1 && nc <= KC_DOWN2_MAX_CHUNKS) {
+        t.d2_nc = nc;
+        t.d2_vrec.assign((size_t)groups * nc * KC_DOWN2_REC, 0u);
+        for (uint32_t g = 0; g < groups; ++g) {
+            const uint32_t y0 = 4u * g, y1 = std::min(out_n, y0 + 4u);
+            uint32_t lo = 0xFFFFFFFFu, hi = 0;
+            for (uint32_t y = y0; y < y1; ++y) {
+                lo = std::min(lo, t.left[y]);
+                hi = std::max(hi, t.left[y] + t.count[y]);
+            }
+            const uint32_t used = (hi - lo + 15u) / 16u;
+            for (uint32_t ch = 0; ch < nc; ++ch) {
+                uint32_t *r = &t.d2_vrec[((size_t)g * nc + ch) * KC_DOWN2_REC];
+                const uint32_t s0 = std::min(lo + 16u * ch, hi - 1u);
+                uint64_t mask = 0;
+                if (ch < used)
+                    for (uint32_t u = 0; u < 16u; ++u)
+                        for (uint32_t y = y0; y < y1; ++y) {
+                            const uint32_t s = s0 + u;
+                            if (s >= t.left[y] && s < t.left[y] + t.count[y]) {
+                                mask |= 1ull << (4u * u + (y - y0));
+                                std::memcpy(&r[8u + 4u * u + (y - y0)], &t.w[(size_t)y * t.stride + (s - t.left[y])], sizeof(float));
+                            }
+                        }
+                r[0] = s0;
+                r[1] = (uint32_t)mask;
+                r[2] = (uint32_t)(mask >> 32);
+                r[3] = hi - 1u;
+                r[4] = used;
+            }
+        }
+    }
+    const uint32_t hs = (t.stride + 3u) / 4u * 4u;
+    if (hs / 4u > 8u) return;
+    t.d2_hstride = hs;
+    t.d2_hw.assign((size_t)out_n * hs, 0.0f);
+    for (uint32_t x = 0; x < out_n; ++x)
+        std::copy(t.w.begin() + (size_t)x * t.stride, t.w.begin() + (size_t)x * t.stride + t.count[x], t.d2_hw.begin() + (size_t)x * hs);
+    // the widest strip whose source window is at most 64 quads (one per lane of the vertical pass), then evened out over the
+    // strips it takes
+    const uint32_t cap = 64u * down2_cols_per_lane(hs / 4u);
+    for (uint32_t tw = std::min(cap, out_n); tw >= 1; --tw)
+        if (tile_groups(t, out_n, tw) <= 64u) {
+            const uint32_t strips = (out_n + tw - 1) / tw, even = (out_n + strips - 1) / strips;
+            t.d2_tile_w = tile_groups(t, out_n, even) <= 64u ? even : tw;
+            break;
+        }
+}
+
 int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
 {
     float (*kern)(float) = nullptr;
@@ -182,6 +266,7 @@ int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
         }
     }
     up_axis_build(in_n, out_n, t);
+    down2_build(out_n, t);
     return KC_OK;
 }
 
@@ -198,7 +283,10 @@ static int taps_upload(TapsEntry &e, bool pooled = false)
     const size_t nu = e.host.up_ok ? e.host.up_rows.size() * sizeof(float) : 0;
     const size_t nu_pad = (nu + 255) / 256 * 256;
     const size_t nuq = e.host.up_ok ? e.host.up_qrows.size() * sizeof(float) : 0;
-    e.dev_bytes = 2 * nl_pad + nw_pad + nu_pad + (nuq + 255) / 256 * 256;
+    const size_t nuq_pad = (nuq + 255) / 256 * 256;
+    const size_t nd2v = e.host.d2_vrec.size() * sizeof(uint32_t), nd2v_pad = (nd2v + 255) / 256 * 256;
+    const size_t nd2h = e.host.d2_hw.size() * sizeof(float);
+    e.dev_bytes = 2 * nl_pad + nw_pad + nu_pad + nuq_pad + nd2v_pad + (nd2h + 255) / 256 * 256;
     if (pooled) {
         KC_TRY(pool_alloc(e.dev_bytes, &e.dev_block));
         c.bytes_in_use -= e.dev_bytes;
@@ -212,6 +300,9 @@ static int taps_upload(TapsEntry &e, bool pooled = false)
     if (err == hipSuccess && nu) err = hipMemcpyAsync(base + 2 * nl_pad + nw_pad, e.host.up_rows.data(), nu, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess && nuq)
         err = hipMemcpyAsync(base + 2 * nl_pad + nw_pad + nu_pad, e.host.up_qrows.data(), nuq, hipMemcpyHostToDevice, c.stream);
+    char *d2v = base + 2 * nl_pad + nw_pad + nu_pad + nuq_pad, *d2h = d2v + nd2v_pad;
+    if (err == hipSuccess && nd2v) err = hipMemcpyAsync(d2v, e.host.d2_vrec.data(), nd2v, hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess && nd2h) err = hipMemcpyAsync(d2h, e.host.d2_hw.data(), nd2h, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
     if (err != hipSuccess) {
         if (pooled) {
@@ -227,6 +318,8 @@ static int taps_upload(TapsEntry &e, bool pooled = false)
     e.dev.count = (const uint32_t *)(base + nl_pad);
     e.dev.w = (const float *)(base + 2 * nl_pad);
     e.dev.stride = e.host.stride;
+    e.host.d2_vrec_dev = nd2v ? (const uint32_t *)d2v : nullptr;
+    e.host.d2_hw_dev = nd2h ? (const float *)d2h : nullptr;
     if (nu) e.host.up.cls = (const float *)(base + 2 * nl_pad + nw_pad);
     if (nuq) e.host.up.qcls = (const float *)(base + 2 * nl_pad + nw_pad + nu_pad);
     return KC_OK;
@@ -297,6 +390,7 @@ static int get_band_taps(uint32_t in_n, uint32_t out_n, int filter, int32_t a, i
         std::copy(full->host.w.begin() + (size_t)oy * stride, full->host.w.begin() + (size_t)(oy + 1) * stride,
                   e.host.w.begin() + (size_t)i * stride);
     }
+    down2_build(rows, e.host);
     KC_TRY(taps_upload(e, true));
     // Bands come in a handful of shapes per graph; bound what a long-lived process keeps.  The least recently used table
     // goes, ONE at a time, and its block returns to the stream-ordered pool: kernels already enqueued may still read it (whoever
@@ -315,19 +409,6 @@ static int get_band_taps(uint32_t in_n, uint32_t out_n, int filter, int32_t a, i
     auto ins = c.band_taps.emplace(key, std::move(e));
     *out = &ins.first->second;
     return KC_OK;
-}
-
-// The widest source-column window any tile_w-wide output tile needs, measured from its first column
-// rounded down to a multiple of 4, in whole 4-column groups.
-static uint32_t tile_groups(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
-{
-    uint32_t groups = 1;
-    for (uint32_t x0 = 0; x0 < out_n; x0 += tile_w) {
-        const uint32_t x1 = std::min(out_n, x0 + tile_w);
-        const uint32_t n = (h.left[x1 - 1] + h.count[x1 - 1] - (h.left[x0] & ~3u) + 3u) / 4u;
-        if (n > groups) groups = n;
-    }
-    return groups;
 }
 
 // LDS pitch in floats for such tiles; an odd group count staggers consecutive tile rows over the banks.
@@ -520,6 +601,28 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 rp.dst[i] = dsts[i]->dptr;
                 rp.spitch[i] = (uint32_t)(srcs[i]->pitch / 4);
                 rp.dpitch[i] = (uint32_t)(dsts[i]->pitch / 4);
+            }
+            // both axes down-sampled: the wave-private form where its tables exist (down2.hip)
+            if (t.down && c.down2 > (t.poly ? 1 : 0) && tv->host.d2_nc && tv->host.d2_vrec_dev && th->host.d2_tile_w &&
+                th->host.d2_hw_dev) {
+                Down2Args a{};
+                a.vrec = tv->host.d2_vrec_dev;
+                a.nc = tv->host.d2_nc;
+                a.hleft = th->dev.left;
+                a.hcount = th->dev.count;
+                a.hw = th->host.d2_hw_dev;
+                a.hstride = th->host.d2_hstride;
+                a.hmin = th->host.min_count;
+                a.hmax = th->host.stride;
+                a.tile_w = th->host.d2_tile_w;
+                a.dw = size.width;
+                a.dh = size.height;
+                hipError_t e2 = launch_resize_down2(rp, n, a, c.stream);
+                if (e2 != hipSuccess) return hip_fail(e2, "launch_resize_down2");
+                c.launches++;
+                c.counters["down2_launches"]++;
+                c.alg_bytes += (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height);
+                return KC_OK;
             }
             hipError_t e = t.poly ? launch_resize_poly(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.ncp, tv->host.reg_a,
                                                        tv->host.reg_b, tv->host.reg_ages, tv->host.reg_ratio, c.stream)
