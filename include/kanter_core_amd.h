@@ -144,8 +144,8 @@ KC_API int kc_get_cache_policy(void);
  *   "replay" 1 (default): an evaluation that repeats the previous one of the same node exactly (same graph by content, same
  *   node states, same slot data and embedded images by identity) skips the node-by-node walk of src/engine.rs:200-307 and
  *   re-issues the recorded launches; 0: always walk.
- *   "down2" 0 / 1 (default) / 2: down-sampling with more than 8 taps on both axes runs resize_down2_kernel never / where the
- *   integer-ratio streaming kernel does not apply / wherever its tables exist (bit-identical; A/B and tests). */
+ *   "down2" 0 / 1 (default) / 2: down-sampling with more than 8 taps on both axes runs resize_down2_kernel never / except
+ *   where the integer-ratio streaming kernel runs at ratio 4 or 8 / wherever its tables exist (bit-identical; A/B and tests). */
 KC_API int kc_set_option(const char *name, int value);
 KC_API int kc_get_option(const char *name, int *value);
 /* Diagnostics (host only, works without a device): the structure the integer-ratio up-sampling kernels rely on,

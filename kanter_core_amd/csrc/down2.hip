@@ -1,4 +1,4 @@
-// Down-sampling on both axes (more than 8 taps each way; image::imageops::resize of crate image 0.24.0 as called from
+// Down-sampling on both axes (windows of 4 taps or more each way; image::imageops::resize of crate image 0.24.0 as called from
 // src/shared.rs:159-199), third form: every WAVE is a job of its own -- no workgroup barrier, no staging shared between waves.
 //
 // What bounded resize_down_kernel (profiles/r03_down_lds_experiment.txt) was not traffic but a wave's chain of dependent
@@ -26,12 +26,12 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float d2_clamp(float t)
+// image::math::utils::clamp(t, 0, 1) for a t that is never -0.0 (a sum that started at +0.0): the IEEE-754-2019 maximum / minimum
+// (v_maximum3_f32 / v_minimum3_f32) pass a NaN through, which is what the reference's two comparisons do (as up_clamp01).
+__device__ __forceinline__ f4 d2_clamp(f4 t)
 {
-    // image::math::utils::clamp: NaN compares false both ways and passes through.
-    if (t < 0.0f) return 0.0f;
-    if (t > 1.0f) return 1.0f;
-    return t;
+    const f4 zero = { 0.0f, 0.0f, 0.0f, 0.0f }, one = { 1.0f, 1.0f, 1.0f, 1.0f };
+    return __builtin_elementwise_minimum(__builtin_elementwise_maximum(t, zero), one);
 }
 
 typedef uint32_t u16v __attribute__((ext_vector_type(16)));
@@ -43,61 +43,75 @@ __device__ __forceinline__ d2_const_u32 d2_const(const uint32_t *p)
 }
 }  // namespace
 
-template <int HC, int NW4, bool EARLY_W>
+// The columns' weights are loaded AFTER the vertical pass (4-5 waves per SIMD).  Loading them behind the row loads, in flight
+// during the arithmetic, costs a wave per SIMD and measured the same or slower (28.5 against 27.7 us on Lanczos3 4096^2 ->
+// 3000^2), and so did loading them half way through the arithmetic (profiles/r03_down2_variants.txt).
+template <int HC, int NW4, bool ONE>  // ONE: every row group has a single chunk (ratios below about 1.6)
 __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P, const Down2Args A)
 {
     __shared__ f4 T[4][KC_DOWN2_SLOTS];  // wave-private: T[wave][source column of the strip] = (row 0, 1, 2, 3)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    const uint32_t g = blockIdx.y * 4u + wave;  // row group: output rows 4 g .. 4 g + 3
-    if (4u * g >= A.dh) return;                 // (no barrier anywhere in this kernel)
-    const uint32_t x0 = blockIdx.x * A.tile_w, x1 = min(x0 + A.tile_w, A.dw);
-    const d2_const_u32 hl = d2_const(A.hleft), hn = d2_const(A.hcount);
-    const uint32_t c0 = hl[x0] & ~3u;
-    const uint32_t nq = (hl[x1 - 1u] + hn[x1 - 1u] - c0 + 3u) / 4u;  // <= 64 (host-checked)
+    // Which tile: workgroups go to the 8 XCDs in turn (id % 8), each XCD with an L2 of its own, and vertically adjacent tiles
+    // share 9 of their ~30 source rows.  With xcd_per set the grid is one-dimensional and XCD k works through the k-th
+    // eighth of the tiles in strip-major order, so that the rows two neighbours share are fetched into one L2, once.
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (A.xcd_per) {
+        const uint32_t tile = (blockIdx.x & 7u) * A.xcd_per + (blockIdx.x >> 3);
+        if (tile >= A.n_tiles) return;
+        bx = __umulhi(tile, A.gy_magic);  // tile / gy (host-checked to be exact for every tile)
+        by = tile - bx * A.gy;
+    }
+    const uint32_t g = by * 4u + wave;  // row group: output rows 4 g .. 4 g + 3
+    if (4u * g >= A.dh) return;         // (no barrier anywhere in this kernel)
+    const uint32_t x0 = bx * A.tile_w, x1 = min(x0 + A.tile_w, A.dw);
+    // the strip's first source column (a multiple of 4) and its width in quads (<= 64), and the group's first record: two
+    // scalar loads whose addresses depend on the block and wave index only, in flight together
+    const d2_const_u32 strip = d2_const(A.strips) + 2u * bx;
+    const d2_const_u32 rec0 = d2_const(A.vrec) + (size_t)g * A.nc * KC_DOWN2_REC;
+    const uint32_t c0 = strip[0], nq = strip[1];
+    const uint32_t nch = rec0[4];
     const uint32_t z = blockIdx.z;
-    const uint32_t sp4 = P.spitch[z] / 4u;
-    const f4 *col = reinterpret_cast<const f4 *>(P.src[z] + c0) + min(lane, nq - 1u);
+    // rows are addressed as (uniform row base) + (this lane's quad): the row bases stay in scalar registers
+    const float *src0 = P.src[z] + c0;
+    const uint32_t spitch = P.spitch[z];
+    const uint32_t qi = min(lane, nq - 1u);
 
     // ---- this lane's output columns: window start, tap count, weights ----
     uint32_t h0[HC], n[HC];
-    const f4 *wrow[HC];
     f4 w[HC][NW4];
+    auto columns = [&]() {
 #pragma unroll
-    for (int c = 0; c < HC; ++c) {
-        const uint32_t x = min(x0 + lane + 64u * c, x1 - 1u);
-        h0[c] = A.hleft[x] - c0;
-        n[c] = A.hcount[x];
-        wrow[c] = reinterpret_cast<const f4 *>(A.hw + (size_t)x * A.hstride);
-    }
+        for (int c = 0; c < HC; ++c) {
+            const uint32_t x = min(x0 + lane + 64u * c, x1 - 1u);
+            h0[c] = A.hleft[x] - c0;
+            n[c] = A.hcount[x];
+            const f4 *wrow = reinterpret_cast<const f4 *>(A.hw + (size_t)x * A.hstride);
+#pragma unroll
+            for (int i = 0; i < NW4; ++i) w[c][i] = wrow[i];
+        }
+    };
 
     // the slots past the 256 a wave fills are read by the last columns' padded taps: zero weights, so any finite value will do
     if (lane < KC_DOWN2_SLOTS - 256u) T[wave][256u + lane] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
     // ---- vertical pass ----
-    const d2_const_u32 rec0 = d2_const(A.vrec) + (size_t)g * A.nc * KC_DOWN2_REC;
-    const uint32_t nch = rec0[4];
     f2 alo[4], ahi[4];  // sums of the quad's columns 0, 1 and 2, 3 for the four rows (pairs: one packed operation each)
 #pragma unroll
     for (int k = 0; k < 4; ++k) alo[k] = ahi[k] = f2{ 0.0f, 0.0f };
-    for (uint32_t ch = 0; ch < nch; ++ch) {
+    for (uint32_t ch = 0; ch < (ONE ? 1u : nch); ++ch) {
         const d2_const_u32 r = rec0 + ch * KC_DOWN2_REC;
         const uint32_t s0 = r[0], last = r[3];
         const uint64_t mask = (uint64_t)r[1] | ((uint64_t)r[2] << 32);  // bit 4 u + k: output row k has a tap on source row s0 + u
         f4 p[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) p[u] = col[(size_t)min(s0 + (uint32_t)u, last) * sp4];
+        for (int u = 0; u < 16; ++u)
+            p[u] = reinterpret_cast<const f4 *>(src0 + (size_t)min(s0 + (uint32_t)u, last) * spitch)[qi];
         // the chunk's 64 weights: four scalar loads in flight behind the row loads (left to itself the compiler fetches them
         // one after the other into the same registers, each with a wait of its own, between the arithmetic)
         u16v W[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) W[i] = *reinterpret_cast<d2_const_u16v>(r + 8 + 16 * i);
         asm volatile("" ::"s"(W[0]), "s"(W[1]), "s"(W[2]), "s"(W[3]));
-        if (EARLY_W && ch == 0u) {
-#pragma unroll
-            for (int c = 0; c < HC; ++c)
-#pragma unroll
-                for (int i = 0; i < NW4; ++i) w[c][i] = wrow[c][i];
-        }
         // A tap that output row k does not have carries the weight +0.0 in the record.  Its product is +-0 and adding that
         // to a sum that started at +0.0 never changes it (such a sum is never -0.0) -- as long as the sample is finite.
         // One test per chunk finds the waves for which that fails; they take the exact form below.
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
         }
         if (__builtin_amdgcn_ballot_w64(!(big < __builtin_inff())) == 0ull) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+            for (int u = 0; u < 16; ++u) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t wbits = W[u >> 2][4 * (u & 3) + k];  // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
@@ -117,6 +131,7 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
                     alo[k] += f2{ p[u].x, p[u].y } * wt;
                     ahi[k] += f2{ p[u].z, p[u].w } * wt;
                 }
+            }
         } else {
             // some sample of the chunk is infinite or NaN: absent taps are left out by a per-lane select (the mask is the
             // same in every lane; as a vector value it keeps this arm free of branches)
@@ -136,12 +151,7 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
                 }
         }
     }
-    if (!EARLY_W) {
-#pragma unroll
-        for (int c = 0; c < HC; ++c)
-#pragma unroll
-            for (int i = 0; i < NW4; ++i) w[c][i] = wrow[c][i];
-    }
+    columns();
 
     // ---- transposition through the wave's own LDS ----
     f4 *Tw = T[wave];
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- horizontal pass ----
-    float *dst = P.dst[z] + (size_t)(4u * g) * P.dpitch[z];
+    float *dst0 = P.dst[z] + (size_t)(4u * g) * P.dpitch[z] + x0;  // (uniform)
     const uint32_t rows = min(4u, A.dh - 4u * g);
     f4 sum[HC];
     if (finite) {
@@ -191,11 +201,11 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
     }
 #pragma unroll
     for (int c = 0; c < HC; ++c) {
-        const uint32_t x = x0 + lane + 64u * c;
-        if (x < x1) {
+        if (x0 + lane + 64u * c < x1) {
+            const f4 v = d2_clamp(sum[c]);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if ((uint32_t)k < rows) dst[(size_t)k * P.dpitch[z] + x] = d2_clamp(sum[c][k]);
+                if ((uint32_t)k < rows) (dst0 + (size_t)k * P.dpitch[z] + 64u * c)[lane] = v[k];
         }
     }
 }
@@ -205,19 +215,37 @@ hipError_t launch_resize_down2(const ResizePlanes &p, int batch, const Down2Args
     if (a.dw == 0 || a.dh == 0) return hipSuccess;
     if (batch < 1 || batch > 4) return hipErrorInvalidValue;
     const uint32_t nw4 = a.hstride / 4u;
-    if (a.hstride % 4u != 0 || nw4 < 3 || nw4 > 8 || a.nc < 1 || a.nc > KC_DOWN2_MAX_CHUNKS || a.tile_w == 0 || a.hmax > a.hstride ||
-        a.hmin > a.hmax)
+    if (a.hstride % 4u != 0 || nw4 < 1 || nw4 > 8 || a.nc < 1 || a.nc > KC_DOWN2_MAX_CHUNKS || a.tile_w == 0 || !a.strips)
         return hipErrorInvalidValue;
     const uint32_t hc = down2_cols_per_lane(nw4);
     if (a.tile_w > 64u * hc) return hipErrorInvalidValue;
     dim3 grid((a.dw + a.tile_w - 1) / a.tile_w, (a.dh + 15u) / 16u, batch);
-    static const bool early = !(std::getenv("KC_DOWN2_LATE_W") && std::atoi(std::getenv("KC_DOWN2_LATE_W")) != 0);
-#define KC_D2(HC, NW4)                                                        \
-    do {                                                                      \
-        if (early) resize_down2_kernel<HC, NW4, true><<<grid, 256, 0, s>>>(p, a);  \
-        else resize_down2_kernel<HC, NW4, false><<<grid, 256, 0, s>>>(p, a);       \
+    Down2Args a2 = a;
+    // KC_DOWN2_XCD=0 / 1: never / always (A/B); default: when the planes fit the Infinity Cache (a.xcd_per as the caller's hint).
+    // Measured (profiles/r03_down2_xcd.txt): one 4096^2 plane 27.9 -> 26.2 us, 3000^2 -> 700^2 17.9 -> 15.4; four 4096^2 planes
+    // (268 MB of source, past the cache) 114.6 -> 122.7: there the plain order, whole rows at a time, is kinder to HBM.
+    static const int xcd_env = std::getenv("KC_DOWN2_XCD") ? std::atoi(std::getenv("KC_DOWN2_XCD")) : -1;
+    const bool xcd = xcd_env < 0 ? a.xcd_per != 0 : xcd_env != 0;
+    a2.xcd_per = 0;
+    if (xcd && grid.y >= 2) {
+        const uint64_t n = (uint64_t)grid.x * grid.y, magic = ((1ull << 32) + grid.y - 1) / grid.y;
+        // tile / gy == (tile * magic) >> 32 for every tile < n when n * (magic * gy - 2^32) < 2^32
+        if (n < (1u << 24) && n * (magic * grid.y - (1ull << 32)) < (1ull << 32)) {
+            a2.n_tiles = (uint32_t)n;
+            a2.gy = grid.y;
+            a2.gy_magic = (uint32_t)magic;
+            a2.xcd_per = (uint32_t)((n + 7) / 8);
+            grid = dim3(8u * a2.xcd_per, 1, batch);
+        }
+    }
+#define KC_D2(HC, NW4)                                                                     \
+    do {                                                                                   \
+        if (a.nc == 1) resize_down2_kernel<HC, NW4, true><<<grid, 256, 0, s>>>(p, a2);     \
+        else resize_down2_kernel<HC, NW4, false><<<grid, 256, 0, s>>>(p, a2);              \
     } while (0)
     switch (nw4) {
+    case 1: KC_D2(3, 1); break;
+    case 2: KC_D2(3, 2); break;
     case 3: KC_D2(3, 3); break;
     case 4: KC_D2(2, 4); break;
     case 5: KC_D2(1, 5); break;

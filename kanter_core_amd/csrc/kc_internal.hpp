@@ -87,13 +87,18 @@ struct ResizePlanes {
 //            mask of tap (source row u, output row k) at bit 4 u + k, [3] the group's last window row (loads are clamped to
 //            it), [4] chunks this group uses, [8 + 4 u + k] the weight (resize.cpp, down2_build)
 //   hw       the horizontal table's weights, rows padded to hstride (a multiple of 4) floats
+//   strips   per strip of tile_w output columns: its first source column rounded down to a multiple of 4, and the width of its
+//            source window in column quads (<= 64: one per lane of the vertical pass)
 constexpr uint32_t KC_DOWN2_REC = 72, KC_DOWN2_MAX_CHUNKS = 4, KC_DOWN2_SLOTS = 256 + 32;
 struct Down2Args {
     const uint32_t *vrec;
-    const uint32_t *hleft, *hcount;
+    const uint32_t *hleft, *hcount, *strips;
     const float *hw;
-    uint32_t nc, hstride, hmin, hmax;  // hmin / hmax: fewest / most taps of any output column
+    uint32_t nc, hstride;
     uint32_t tile_w, dw, dh;
+    // XCD-aware tile order (down2.hip).  The caller sets xcd_per != 0 to ask for it; the launcher fills in the rest (or clears
+    // xcd_per: plain 2-D grid).
+    uint32_t xcd_per, n_tiles, gy, gy_magic;
 };
 // output columns per lane of the horizontal pass: its weights live in registers (at most 9 quads per lane)
 inline uint32_t down2_cols_per_lane(uint32_t weight_quads) { return weight_quads <= 3 ? 3u : weight_quads == 4 ? 2u : 1u; }

@@ -167,16 +167,17 @@ struct TapsHost {
     bool up_ok = false;
     UpAxis up{};
     std::vector<float> up_rows, up_qrows;  // class rows per output / per column quad (tap-major)
-    // resize_down2_kernel (down2.hip; built by down2_build when the table has more than KC_RESIZE_REG_TAPS taps):
+    // resize_down2_kernel (down2.hip; built by down2_build for down-sampling axes, d2_want):
     //   as the VERTICAL table   d2_vrec: d2_nc records of KC_DOWN2_REC dwords per group of four output rows (kc_internal.hpp);
     //                           d2_nc == 0: some group's windows span more than KC_DOWN2_MAX_CHUNKS x 16 source rows (wrapped
     //                           rows of a band table, very large ratios)
     //   as the HORIZONTAL table d2_hw: the weights with rows padded to d2_hstride (a multiple of 4, +0.0 beyond a column's own
     //                           taps); d2_tile_w: the strip width whose widest source window is 64 quads (0: none)
-    std::vector<uint32_t> d2_vrec;
+    std::vector<uint32_t> d2_vrec, d2_strips;  // d2_strips: (first source column & ~3, source quads) per strip of d2_tile_w columns
     std::vector<float> d2_hw;
+    bool d2_want = false;  // a down-sampling axis with windows of at least 4 taps
     uint32_t d2_nc = 0, d2_hstride = 0, d2_tile_w = 0;
-    const uint32_t *d2_vrec_dev = nullptr;
+    const uint32_t *d2_vrec_dev = nullptr, *d2_strips_dev = nullptr;
     const float *d2_hw_dev = nullptr;
 };
 
@@ -215,7 +216,7 @@ struct Context {
     hipStream_t stream = nullptr;
     bool fusion = true;
     bool replay = true;  // an evaluation that repeats the recorded one is replayed without the walk (kc_set_option("replay", 0); env KC_REPLAY)
-    int down2 = 1;       // resize_down2_kernel: 0 off, 1 where resize_poly_kernel does not apply, 2 there too (kc_set_option("down2"); env KC_DOWN2)
+    int down2 = 1;       // resize_down2_kernel: 0 off, 1 except where resize_poly_kernel runs at ratio 4 or 8, 2 there too (kc_set_option("down2"); env KC_DOWN2)
     bool chain1 = true;  // one-step programs run the ahead-of-time kernels of chain1.hip (kc_set_option("chain1", 0): interpreter / specialiser, A/B and tests)
     int cache_policy = 1;  // 1: launches whose streams exceed the Infinity Cache mark them nontemporal (cache_policy_mask); 0: plain loads / stores (KC_CACHE_POLICY, kc_set_cache_policy)
     int max_blocks = 4096;

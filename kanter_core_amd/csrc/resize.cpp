@@ -119,7 +119,7 @@ static uint32_t tile_groups(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
     return groups;
 }
 
-// What resize_down2_kernel (down2.hip) reads instead of the plain table, for tables of more than KC_RESIZE_REG_TAPS taps.
+// What resize_down2_kernel (down2.hip) reads instead of the plain table, for the tables of down-sampling axes (d2_want).
 // Vertical use: per group of four output rows the union of their windows in chunks of 16 source rows; record (group, chunk)
 // holds the weight of tap (source row u of the chunk, output row k of the group) at [8 + 4 u + k] -- +0.0 and a clear mask
 // bit where row k has no tap on that source row -- so the kernel needs no per-tap look-up.  The weights are the table's own
@@ -129,8 +129,9 @@ void down2_build(uint32_t out_n, TapsHost &t)
 {
     t.d2_nc = t.d2_hstride = t.d2_tile_w = 0;
     t.d2_vrec.clear();
+    t.d2_strips.clear();
     t.d2_hw.clear();
-    if (t.stride <= KC_RESIZE_REG_TAPS || out_n == 0) return;
+    if (!t.d2_want || out_n == 0) return;
     const uint32_t groups = (out_n + 3u) / 4u;
     uint32_t nc = 0;
     for (uint32_t g = 0; g < groups; ++g) {
@@ -188,6 +189,11 @@ void down2_build(uint32_t out_n, TapsHost &t)
             t.d2_tile_w = tile_groups(t, out_n, even) <= 64u ? even : tw;
             break;
         }
+    for (uint32_t x0 = 0; t.d2_tile_w && x0 < out_n; x0 += t.d2_tile_w) {
+        const uint32_t x1 = std::min(out_n, x0 + t.d2_tile_w), c0 = t.left[x0] & ~3u;
+        t.d2_strips.push_back(c0);
+        t.d2_strips.push_back((t.left[x1 - 1] + t.count[x1 - 1] - c0 + 3u) / 4u);
+    }
 }
 
 int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
@@ -266,6 +272,7 @@ int build_taps_host(uint32_t in_n, uint32_t out_n, int filter, TapsHost &t)
         }
     }
     up_axis_build(in_n, out_n, t);
+    t.d2_want = in_n > out_n && t.stride >= 4;  // a down-sampling axis with windows of 4 taps or more (Triangle from ratio 1.5 on)
     down2_build(out_n, t);
     return KC_OK;
 }
@@ -285,8 +292,9 @@ static int taps_upload(TapsEntry &e, bool pooled = false)
     const size_t nuq = e.host.up_ok ? e.host.up_qrows.size() * sizeof(float) : 0;
     const size_t nuq_pad = (nuq + 255) / 256 * 256;
     const size_t nd2v = e.host.d2_vrec.size() * sizeof(uint32_t), nd2v_pad = (nd2v + 255) / 256 * 256;
-    const size_t nd2h = e.host.d2_hw.size() * sizeof(float);
-    e.dev_bytes = 2 * nl_pad + nw_pad + nu_pad + nuq_pad + nd2v_pad + (nd2h + 255) / 256 * 256;
+    const size_t nd2h = e.host.d2_hw.size() * sizeof(float), nd2h_pad = (nd2h + 255) / 256 * 256;
+    const size_t nd2s = e.host.d2_strips.size() * sizeof(uint32_t);
+    e.dev_bytes = 2 * nl_pad + nw_pad + nu_pad + nuq_pad + nd2v_pad + nd2h_pad + (nd2s + 255) / 256 * 256;
     if (pooled) {
         KC_TRY(pool_alloc(e.dev_bytes, &e.dev_block));
         c.bytes_in_use -= e.dev_bytes;
@@ -300,7 +308,8 @@ static int taps_upload(TapsEntry &e, bool pooled = false)
     if (err == hipSuccess && nu) err = hipMemcpyAsync(base + 2 * nl_pad + nw_pad, e.host.up_rows.data(), nu, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess && nuq)
         err = hipMemcpyAsync(base + 2 * nl_pad + nw_pad + nu_pad, e.host.up_qrows.data(), nuq, hipMemcpyHostToDevice, c.stream);
-    char *d2v = base + 2 * nl_pad + nw_pad + nu_pad + nuq_pad, *d2h = d2v + nd2v_pad;
+    char *d2v = base + 2 * nl_pad + nw_pad + nu_pad + nuq_pad, *d2h = d2v + nd2v_pad, *d2s = d2h + nd2h_pad;
+    if (err == hipSuccess && nd2s) err = hipMemcpyAsync(d2s, e.host.d2_strips.data(), nd2s, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess && nd2v) err = hipMemcpyAsync(d2v, e.host.d2_vrec.data(), nd2v, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess && nd2h) err = hipMemcpyAsync(d2h, e.host.d2_hw.data(), nd2h, hipMemcpyHostToDevice, c.stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
@@ -320,6 +329,7 @@ static int taps_upload(TapsEntry &e, bool pooled = false)
     e.dev.stride = e.host.stride;
     e.host.d2_vrec_dev = nd2v ? (const uint32_t *)d2v : nullptr;
     e.host.d2_hw_dev = nd2h ? (const float *)d2h : nullptr;
+    e.host.d2_strips_dev = nd2s ? (const uint32_t *)d2s : nullptr;
     if (nu) e.host.up.cls = (const float *)(base + 2 * nl_pad + nw_pad);
     if (nuq) e.host.up.qcls = (const float *)(base + 2 * nl_pad + nw_pad + nu_pad);
     return KC_OK;
@@ -390,6 +400,7 @@ static int get_band_taps(uint32_t in_n, uint32_t out_n, int filter, int32_t a, i
         std::copy(full->host.w.begin() + (size_t)oy * stride, full->host.w.begin() + (size_t)(oy + 1) * stride,
                   e.host.w.begin() + (size_t)i * stride);
     }
+    e.host.d2_want = full->host.d2_want;
     down2_build(rows, e.host);
     KC_TRY(taps_upload(e, true));
     // Bands come in a handful of shapes per graph; bound what a long-lived process keeps.  The least recently used table
@@ -603,8 +614,11 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 rp.dpitch[i] = (uint32_t)(dsts[i]->pitch / 4);
             }
             // both axes down-sampled: the wave-private form where its tables exist (down2.hip)
-            if (t.down && c.down2 > (t.poly ? 1 : 0) && tv->host.d2_nc && tv->host.d2_vrec_dev && th->host.d2_tile_w &&
-                th->host.d2_hw_dev) {
+            // ... except where the streaming kernel of integer ratios is the faster one: ratios 4 and 8 (Lanczos3 4096^2 -> 1024^2
+            // 23.5 against 26.7 us, CatmullRom 18.1 / 21.4; at ratio 2 down2 wins, 26.3 / 30.4 -- profiles/r03_down2_ab.txt)
+            const bool poly_first = t.poly && tv->host.reg_ratio >= 4;
+            if (c.down2 > (poly_first ? 1 : 0) && tv->host.d2_nc && tv->host.d2_vrec_dev && th->host.d2_tile_w &&
+                th->host.d2_hw_dev && th->host.d2_strips_dev) {
                 Down2Args a{};
                 a.vrec = tv->host.d2_vrec_dev;
                 a.nc = tv->host.d2_nc;
@@ -612,11 +626,12 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 a.hcount = th->dev.count;
                 a.hw = th->host.d2_hw_dev;
                 a.hstride = th->host.d2_hstride;
-                a.hmin = th->host.min_count;
-                a.hmax = th->host.stride;
+                a.strips = th->host.d2_strips_dev;
                 a.tile_w = th->host.d2_tile_w;
                 a.dw = size.width;
                 a.dh = size.height;
+                // tiles in XCD order while source and result stay in the Infinity Cache (the budget of the cache policy)
+                a.xcd_per = (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height) <= (208ull << 20) ? 1u : 0u;
                 hipError_t e2 = launch_resize_down2(rp, n, a, c.stream);
                 if (e2 != hipSuccess) return hip_fail(e2, "launch_resize_down2");
                 c.launches++;

@@ -9,7 +9,8 @@ import kanter_core_amd as kc
 
 CASES = [(4096, 3000, "Lanczos3"), (4096, 1024, "Lanczos3"), (4096, 1365, "CatmullRom"), (3000, 700, "Gaussian"),
          (4093, 511, "Triangle"), (333, 64, "Lanczos3"), (4096, 2048, "Lanczos3"), (130, 61, "CatmullRom"), (70, 33, "CatmullRom"),
-         (64, 16, "Gaussian"), (37, 13, "Gaussian"), (19, 7, "Lanczos3"), (11, 3, "CatmullRom")]
+         (64, 16, "Gaussian"), (37, 13, "Gaussian"), (19, 7, "Lanczos3"), (11, 3, "CatmullRom"),
+         (4096, 2048, "CatmullRom"), (4096, 2048, "Triangle"), (1030, 515, "Triangle"), (4096, 4000, "Lanczos3"), (300, 290, "Gaussian")]
 
 
 def plan(i, o, f):
@@ -19,7 +20,7 @@ def plan(i, o, f):
 @pytest.mark.parametrize("in_n,out_n,filt", CASES)
 def test_vertical_records_hold_exactly_the_table(in_n, out_n, filt):
     p = plan(in_n, out_n, filt)
-    assert p["stride"] > 8 and 1 <= p["nc"] <= 4
+    assert p["stride"] >= 4 and 1 <= p["nc"] <= 4
     left, count, w, rec = p["left"].astype(np.int64), p["count"].astype(np.int64), p["w"], p["vrec"]
     wbits = w.view(np.uint32)
     for g in range(rec.shape[0]):
@@ -72,7 +73,9 @@ def test_horizontal_rows_and_strip_width(in_n, out_n, filt):
 
 
 def test_tables_that_cannot_be_used_say_so():
-    assert plan(64, 48, "Triangle")["nc"] == 0          # at most 8 taps: the register-tap kernels' ground
-    assert plan(64, 48, "Triangle")["hstride"] == 0
+    assert plan(64, 48, "Nearest")["nc"] == 0           # fewer than 4 taps: the register-tap kernels' ground
+    assert plan(64, 48, "Nearest")["hstride"] == 0
+    assert plan(48, 64, "Lanczos3")["nc"] == 0          # an up-sampling axis (6 taps)
+    assert plan(64, 64, "Lanczos3")["nc"] == 0          # ratio 1
     assert plan(4096, 512, "Gaussian")["nc"] == 0       # 48 taps: four rows' windows span more than 64 samples
     assert plan(333, 41, "Lanczos3")["hstride"] == 0    # 50 taps: more than 32

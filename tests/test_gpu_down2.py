@@ -1,4 +1,4 @@
-"""GPU parity of resize_down2_kernel (csrc/down2.hip) -- down-sampling on both axes with more than 8 taps each way, every wave
+"""GPU parity of resize_down2_kernel (csrc/down2.hip) -- down-sampling on both axes with windows of 4 taps or more each way, every wave
 a job of its own -- against the CPU oracle and against the kernels it replaces (kc.set_option("down2", 0)), bit for bit,
 through the C ABI.  Reference: image::imageops::resize (crate image 0.24.0) as called from src/shared.rs:159-199.
 What is specific to this kernel: absent taps carry zero weights, which is exact only while the samples (vertical pass) and
@@ -20,6 +20,9 @@ CASES = [
     ("Lanczos3", (260, 333), (190, 64)),        # 1.37 across, 5.2 down: 33 vertical taps, windows of four rows in four chunks
     ("CatmullRom", (130, 70), (61, 33)),        # one strip, partial last row group
     ("Gaussian", (64, 64), (16, 16)),
+    ("CatmullRom", (1030, 70), (515, 35)),      # ratio 2: 8-9 taps
+    ("Triangle", (1030, 70), (515, 35)),        # ratio 2: 4 taps, one weight quad per column
+    ("Lanczos3", (300, 200), (290, 193)),       # ratio 1.03: 8 taps, windows of neighbouring rows almost coincide
 ]
 
 

@@ -18,23 +18,24 @@ def usage(tmp_path_factory):
     hipcc = kbuild._hipcc()
     if shutil.which(hipcc) is None and not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("res") / "kernels.o"
-    src = os.path.join(ROOT, "kanter_core_amd", "csrc", "kernels.hip")
-    cmd = [hipcc] + kbuild.FLAGS + kbuild.DEVICE_FLAGS + ["-x", "hip", "-Rpass-analysis=kernel-resource-usage", "-c", src,
-                                                          "-o", str(out)]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout[-2000:]
     table = {}
-    name = None
-    for line in r.stdout.splitlines():
-        m = re.search(r"Function Name: (\S+)", line)
-        if m:
-            name = m.group(1)
-            table[name] = {}
-            continue
-        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
-        if m and name:
-            table[name][m.group(1).split()[0]] = int(m.group(2))
+    tmp = tmp_path_factory.mktemp("res")
+    for unit in ("kernels.hip", "chain1.hip", "down2.hip"):
+        src = os.path.join(ROOT, "kanter_core_amd", "csrc", unit)
+        cmd = [hipcc] + kbuild.FLAGS + kbuild.DEVICE_FLAGS + ["-x", "hip", "-Rpass-analysis=kernel-resource-usage", "-c", src,
+                                                              "-o", str(tmp / (unit + ".o"))]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        name = None
+        for line in r.stdout.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                table[name] = {}
+                continue
+            m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|LDS Size \[bytes/block\]): (\d+)", line)
+            if m and name:
+                table[name][m.group(1).split()[0]] = int(m.group(2))
     return table
 
 
@@ -66,6 +67,25 @@ def test_resize_kernels_fit_their_budgets(usage):
                  "resize_poly_kernelILi6ELi4EEE", "resize_poly_kernelILi6ELi8EEE", "resize_poly_kernelILi2ELi8EEE"):
         (u,) = find(usage, frag)
         assert u["VGPRs"] <= 128, (frag, u)
+
+
+def test_down2_kernels_fit_their_budgets(usage):
+    # resize_down2_kernel<HC, NW4, ONE> (down2.hip): 16 source rows in flight per lane (64 VGPRs) next to 8 packed sums.  The
+    # single-chunk forms must allow 4 waves per SIMD with three columns per lane (Lanczos3 at ratios below 1.6) and 5 otherwise;
+    # nothing may spill, and a workgroup's four wave-private transposition areas are 18 KB of LDS (8 workgroups per CU).
+    seen = 0
+    for name, u in usage.items():
+        if "resize_down2_kernel" not in name:
+            continue
+        seen += 1
+        assert u.get("ScratchSize", 0) == 0, (name, u)
+        assert u["VGPRs"] <= 128, (name, u)
+        assert u["LDS"] <= 20 * 1024, (name, u)
+        if "ILi3ELi3ELb1E" not in name and "Lb1EEE" in name:
+            assert u["VGPRs"] <= 96, (name, u)
+    assert seen == 16
+    (u,) = find(usage, "resize_down2_kernelILi3ELi3ELb1EEE")
+    assert u["VGPRs"] <= 112, u
 
 
 def test_upsample_kernels_fit_their_budgets(usage):
