@@ -164,7 +164,7 @@ KC_API int kc_resize_upsample_plan(uint32_t in_n, uint32_t out_n, int filter, in
  * and strip width when it serves as the HORIZONTAL one (0: it cannot).  Optional outputs: left_count = out_n window starts then
  * out_n tap counts, w = out_n x stride weights of the plain table, vrec = ceil(out_n / 4) x nc records of 72 dwords ([0] first
  * source sample, [1], [2] presence mask of tap (sample u, output k) at bit 4 u + k, [3] last sample of the group's windows, [4]
- * records in use, [8 + 4 u + k] weights), hw = out_n x hstride padded weights; each as many elements as its capacity allows. */
+ * records in use, [5] the same in halves of 8 samples, [8 + 4 u + k] weights), hw = out_n x hstride padded weights; each as many elements as its capacity allows. */
 KC_API int kc_resize_down2_plan(uint32_t in_n, uint32_t out_n, int filter, int32_t info[5], uint32_t *left_count, float *w, size_t wcap,
                                 uint32_t *vrec, size_t vcap, float *hw, size_t hcap);
 /* Pool statistics: bytes currently handed out, bytes cached for reuse, kernels launched. */

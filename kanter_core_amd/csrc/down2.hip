@@ -46,7 +46,8 @@ __device__ __forceinline__ d2_const_u32 d2_const(const uint32_t *p)
 // The columns' weights are loaded AFTER the vertical pass (4-5 waves per SIMD).  Loading them behind the row loads, in flight
 // during the arithmetic, costs a wave per SIMD and measured the same or slower (28.5 against 27.7 us on Lanczos3 4096^2 ->
 // 3000^2), and so did loading them half way through the arithmetic (profiles/r03_down2_variants.txt).
-template <int HC, int NW4, bool ONE>  // ONE: every row group has a single chunk (ratios below about 1.6)
+// MODE 0: every row group has a single chunk (ratios below about 1.6); 1: several, eight rows at a time, pipelined
+template <int HC, int NW4, int MODE>
 __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P, const Down2Args A)
 {
     __shared__ f4 T[4][KC_DOWN2_SLOTS];  // wave-private: T[wave][source column of the strip] = (row 0, 1, 2, 3)
@@ -69,7 +70,6 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
     const d2_const_u32 strip = d2_const(A.strips) + 2u * bx;
     const d2_const_u32 rec0 = d2_const(A.vrec) + (size_t)g * A.nc * KC_DOWN2_REC;
     const uint32_t c0 = strip[0], nq = strip[1];
-    const uint32_t nch = rec0[4];
     const uint32_t z = blockIdx.z;
     // rows are addressed as (uniform row base) + (this lane's quad): the row bases stay in scalar registers
     const float *src0 = P.src[z] + c0;
@@ -98,32 +98,36 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
     f2 alo[4], ahi[4];  // sums of the quad's columns 0, 1 and 2, 3 for the four rows (pairs: one packed operation each)
 #pragma unroll
     for (int k = 0; k < 4; ++k) alo[k] = ahi[k] = f2{ 0.0f, 0.0f };
-    for (uint32_t ch = 0; ch < (ONE ? 1u : nch); ++ch) {
-        const d2_const_u32 r = rec0 + ch * KC_DOWN2_REC;
-        const uint32_t s0 = r[0], last = r[3];
-        const uint64_t mask = (uint64_t)r[1] | ((uint64_t)r[2] << 32);  // bit 4 u + k: output row k has a tap on source row s0 + u
-        f4 p[16];
+    const uint32_t first = rec0[0], last = rec0[3];  // the group's windows span source rows first .. last; loads are clamped to `last`
+    // N rows from `first + row0` on
+    auto fetch = [&](auto &p, uint32_t row0) {
+        constexpr int N = (int)(sizeof(p) / sizeof(f4));
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            p[u] = reinterpret_cast<const f4 *>(src0 + (size_t)min(s0 + (uint32_t)u, last) * spitch)[qi];
-        // the chunk's 64 weights: four scalar loads in flight behind the row loads (left to itself the compiler fetches them
-        // one after the other into the same registers, each with a wait of its own, between the arithmetic)
-        u16v W[4];
+        for (int u = 0; u < N; ++u)
+            p[u] = reinterpret_cast<const f4 *>(src0 + (size_t)min(first + row0 + (uint32_t)u, last) * spitch)[qi];
+    };
+    // ... into the four sums: the N x 4 weights at w (w[4 u + k]: source row u, output row k) and their presence bits at m
+    auto consume = [&](const auto &p, d2_const_u32 w, d2_const_u32 m) {
+        constexpr int N = (int)(sizeof(p) / sizeof(f4));
+        // the weights: N / 4 scalar loads in flight together (left to itself the compiler fetches them one after the other into
+        // the same registers, each with a wait of its own, between the arithmetic)
+        u16v W[N / 4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) W[i] = *reinterpret_cast<d2_const_u16v>(r + 8 + 16 * i);
-        asm volatile("" ::"s"(W[0]), "s"(W[1]), "s"(W[2]), "s"(W[3]));
+        for (int i = 0; i < N / 4; ++i) W[i] = *reinterpret_cast<d2_const_u16v>(w + 16 * i);
+        if constexpr (N == 16) asm volatile("" ::"s"(W[0]), "s"(W[1]), "s"(W[2]), "s"(W[3]));
+        else asm volatile("" ::"s"(W[0]), "s"(W[1]));
         // A tap that output row k does not have carries the weight +0.0 in the record.  Its product is +-0 and adding that
         // to a sum that started at +0.0 never changes it (such a sum is never -0.0) -- as long as the sample is finite.
-        // One test per chunk finds the waves for which that fails; they take the exact form below.
+        // One test finds the waves for which that fails; they take the exact form below.
         float big = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < N; ++u) {
             big = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_fabsf(p[u].x), __builtin_fabsf(p[u].y)), big);
             big = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_fabsf(p[u].z), __builtin_fabsf(p[u].w)), big);
         }
         if (__builtin_amdgcn_ballot_w64(!(big < __builtin_inff())) == 0ull) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < N; ++u) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t wbits = W[u >> 2][4 * (u & 3) + k];  // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
@@ -133,12 +137,13 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
                 }
             }
         } else {
-            // some sample of the chunk is infinite or NaN: absent taps are left out by a per-lane select (the mask is the
-            // same in every lane; as a vector value it keeps this arm free of branches)
-            uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+            // some sample is infinite or NaN: absent taps are left out by a per-lane select (the presence mask -- bit 4 u + k:
+            // output row k has a tap on source row u -- is the same in every lane; as a vector value it keeps this arm free of
+            // branches)
+            uint32_t mlo = m[0], mhi = N == 16 ? m[1] : 0u;
             asm volatile("" : "+v"(mlo), "+v"(mhi));
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+            for (int u = 0; u < N; ++u)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t wbits = W[u >> 2][4 * (u & 3) + k];  // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0)
@@ -149,6 +154,31 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
                     alo[k] += on ? tlo : f2{ 0.0f, 0.0f };
                     ahi[k] += on ? thi : f2{ 0.0f, 0.0f };
                 }
+        }
+    };
+    // half h of the records: rows 8 h .. 8 h + 7 of the group's span, weights and presence bits inside record h / 2
+    auto half_w = [&](uint32_t h) { return rec0 + (h >> 1) * KC_DOWN2_REC + 8u + 32u * (h & 1u); };
+    auto half_m = [&](uint32_t h) { return rec0 + (h >> 1) * KC_DOWN2_REC + 1u + (h & 1u); };
+    if constexpr (MODE == 0) {  // one chunk: its 16 loads are in flight together, the arithmetic follows them as they arrive
+        f4 p[16];
+        fetch(p, 0u);
+        consume(p, rec0 + 8, rec0 + 1);
+    } else {
+        // several chunks, eight rows at a time: the next eight are in flight during the arithmetic on these (16 loads in
+        // flight as above, but a wave's life is one memory latency plus the arithmetic instead of one latency per chunk; 91
+        // registers instead of 105).  Against chunk after chunk: 14.5 / 15.2 us on Gaussian 3000^2 -> 700^2, 24.4 / 26.0 on
+        // Gaussian 4096^2 -> 2048^2, 22.2 / 21.2 on CatmullRom 4:1 (profiles/r03_down2_pipe.txt).  Two whole chunks in registers
+        // (169 of them, 2 waves per SIMD) lost 15-20 % everywhere (r03_down2_pf.txt): this kernel lives on waves in flight.
+        const uint32_t halves = rec0[5];
+        f4 pa[8], pb[8];
+        fetch(pa, 0u);
+        for (uint32_t h = 0; h < halves; h += 2u) {
+            if (h + 1u < halves) fetch(pb, 8u * (h + 1u));
+            consume(pa, half_w(h), half_m(h));
+            if (h + 1u < halves) {
+                if (h + 2u < halves) fetch(pa, 8u * (h + 2u));
+                consume(pb, half_w(h + 1u), half_m(h + 1u));
+            }
         }
     }
     columns();
@@ -240,8 +270,8 @@ hipError_t launch_resize_down2(const ResizePlanes &p, int batch, const Down2Args
     }
 #define KC_D2(HC, NW4)                                                                     \
     do {                                                                                   \
-        if (a.nc == 1) resize_down2_kernel<HC, NW4, true><<<grid, 256, 0, s>>>(p, a2);     \
-        else resize_down2_kernel<HC, NW4, false><<<grid, 256, 0, s>>>(p, a2);              \
+        if (a.nc == 1) resize_down2_kernel<HC, NW4, 0><<<grid, 256, 0, s>>>(p, a2);        \
+        else resize_down2_kernel<HC, NW4, 1><<<grid, 256, 0, s>>>(p, a2);                  \
     } while (0)
     switch (nw4) {
     case 1: KC_D2(3, 1); break;

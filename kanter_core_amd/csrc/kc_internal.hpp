@@ -85,7 +85,7 @@ struct ResizePlanes {
 // resize_down2_kernel (down2.hip): the wave-private form of down-sampling on both axes.
 //   vrec     per group of 4 output rows `nc` records of KC_DOWN2_REC dwords: [0] first source row of the chunk, [1], [2] presence
 //            mask of tap (source row u, output row k) at bit 4 u + k, [3] the group's last window row (loads are clamped to
-//            it), [4] chunks this group uses, [8 + 4 u + k] the weight (resize.cpp, down2_build)
+//            it), [4] chunks this group uses, [5] the same in half chunks of 8 rows, [8 + 4 u + k] the weight (resize.cpp, down2_build)
 //   hw       the horizontal table's weights, rows padded to hstride (a multiple of 4) floats
 //   strips   per strip of tile_w output columns: its first source column rounded down to a multiple of 4, and the width of its
 //            source window in column quads (<= 64: one per lane of the vertical pass)

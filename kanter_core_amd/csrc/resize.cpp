@@ -171,6 +171,7 @@ void down2_build(uint32_t out_n, TapsHost &t)
                 r[2] = (uint32_t)(mask >> 32);
                 r[3] = hi - 1u;
                 r[4] = used;
+                r[5] = (hi - lo + 7u) / 8u;  // ... in half chunks of 8 rows
             }
         }
     }

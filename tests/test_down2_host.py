@@ -28,6 +28,7 @@ def test_vertical_records_hold_exactly_the_table(in_n, out_n, filt):
         lo, hi = min(left[y] for y in rows), max(left[y] + count[y] for y in rows)
         used = int(rec[g, 0, 4])
         assert used == -(-(hi - lo) // 16) and used <= p["nc"]
+        assert int(rec[g, 0, 5]) == -(-(hi - lo) // 8)  # the same span in half chunks (the pipelined form's trip count)
         seen = {y: 0 for y in rows}
         for ch in range(p["nc"]):
             r = rec[g, ch]
