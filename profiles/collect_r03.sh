@@ -39,4 +39,7 @@ rm -rf $R/gpurun_out/pmc; BENCH_EXTRA="--workload resize_blend" bash profiles/ru
 python3 profiles/pmc_to_json.py $R/gpurun_out/pmc $OUT/r03_pmc_upsample_chain_kernel.json 405798912 "bench.py --workload resize_blend (512^2 -> 4096^2 Triangle + 3-node blend chain), warm-up dispatches dropped" kc_upchain_ > /dev/null 2>> $OUT/pmc_rb.log
 rm -rf $R/gpurun_out/pmc
 (KC_SPECIALIZE=2 bash profiles/kernel_times.sh spec; KC_SPECIALIZE=0 KC_CHAIN1=0 bash profiles/kernel_times.sh interp; KC_CACHE_POLICY=0 bash profiles/kernel_times.sh policy_off) > $OUT/r03_kernel_times.txt 2>&1
+bash profiles/resize_kernel_times.sh > $OUT/r03_resize_kernel_times.txt 2>&1
+MODES="0 1" bash profiles/down_ab.sh 2>/dev/null > $OUT/r03_down2_ab.txt
+for s in 256 1024; do python bench.py --workload fanin --size $s --steps 300 --warmup 20 --no-cpu-baseline > $OUT/r03_bench_fanin_$s.json 2>/dev/null; done
 ls -la $OUT
