@@ -107,8 +107,27 @@ hipError_t launch_resize_lds(const ResizePlanes &p, int batch, uint32_t dw, uint
                              uint32_t h_min_count, uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);
 hipError_t launch_resize_down(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,
                               uint32_t tile_h, uint32_t ncp, hipStream_t s);
+// Tiles in XCD order (as resize_down2_kernel's): with per != 0 the grid is one-dimensional, workgroup id % 8 is the XCD and XCD k
+// works through the k-th eighth of the gx x gy tiles in column-major order (tile = (id % 8) * per + id / 8; x = tile / gy), so
+// that vertically adjacent tiles, which share source rows, meet in one L2.
+struct XcdOrder {
+    uint32_t per, n, gy, magic;
+};
+inline XcdOrder xcd_order(uint32_t gx, uint32_t gy, bool want)
+{
+    XcdOrder o{ 0, 0, 0, 0 };
+    if (!want || gy < 2) return o;
+    const uint64_t n = (uint64_t)gx * gy, magic = ((1ull << 32) + gy - 1) / gy;
+    // tile / gy == (tile * magic) >> 32 for every tile < n when n * (magic * gy - 2^32) < 2^32
+    if (n >= (1u << 24) || n * (magic * gy - (1ull << 32)) >= (1ull << 32)) return o;
+    o.per = (uint32_t)((n + 7) / 8);
+    o.n = (uint32_t)n;
+    o.gy = gy;
+    o.magic = (uint32_t)magic;
+    return o;
+}
 hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,
-                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, hipStream_t s);
+                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, bool xcd, hipStream_t s);
 // Fused resample + chain: input slot n_in - 1 of the program is produced by the resampler.
 hipError_t launch_resize_chain(const ChainProgram &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h,
                                uint32_t tile_w, uint32_t tile_h, uint32_t ncp, hipStream_t s);

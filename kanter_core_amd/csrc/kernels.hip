@@ -789,10 +789,10 @@ struct DownStrip {
 };
 
 static __device__ __forceinline__ DownStrip resize_down_stage(float *lds, const TapsDev &H, uint32_t dw, uint32_t tile_w,
-                                                              uint32_t tmp_rows, uint32_t ncp)
+                                                              uint32_t tmp_rows, uint32_t ncp, uint32_t bx)
 {
     DownStrip S;
-    S.x0 = blockIdx.x * tile_w;
+    S.x0 = bx * tile_w;
     const uint32_t x1 = min(S.x0 + tile_w, dw);
     S.tw = x1 - S.x0;
     S.c0 = H.left[S.x0] & ~3u;
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void resize_down_kernel(const ResizePlanes P, 
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr uint32_t tile_h = 4u * R;
-    const DownStrip S = resize_down_stage(lds, H, dw, tile_w, tile_h, ncp);
+    const DownStrip S = resize_down_stage(lds, H, dw, tile_w, tile_h, ncp, blockIdx.x);
     const uint32_t y0 = blockIdx.y * tile_h, th = min(y0 + tile_h, dh) - y0;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     resize_down_tile<R>(S, P.src[blockIdx.z], P.spitch[blockIdx.z], P.dst[blockIdx.z], P.dpitch[blockIdx.z], y0, th, V, wave,
@@ -933,22 +933,29 @@ struct PolyBands {
 
 template <int A, int RT>
 __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
-                                                          TapsDev H, uint32_t tile_w, uint32_t ncp, PolyBands B)
+                                                          TapsDev H, uint32_t tile_w, uint32_t ncp, PolyBands B, XcdOrder X)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const DownStrip S = resize_down_stage(lds, H, dw, tile_w, 16u, ncp);
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (X.per) {  // tiles in XCD order (kc_internal.hpp)
+        const uint32_t tile = (blockIdx.x & 7u) * X.per + (blockIdx.x >> 3);
+        if (tile >= X.n) return;
+        bx = __umulhi(tile, X.magic);
+        by = tile - bx * X.gy;
+    }
+    const DownStrip S = resize_down_stage(lds, H, dw, tile_w, 16u, ncp, bx);
     const float *__restrict__ src = P.src[blockIdx.z];
     float *__restrict__ dst = P.dst[blockIdx.z];
     const uint32_t spitch = P.spitch[blockIdx.z], dpitch = P.dpitch[blockIdx.z];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
-    if (blockIdx.y >= B.nyb) {
-        const uint32_t t = blockIdx.y - B.nyb;
+    if (by >= B.nyb) {
+        const uint32_t t = by - B.nyb;
         resize_down_tile<4>(S, src, spitch, dst, dpitch, B.ty0[t], B.th[t], V, wave, lane);
         return;
     }
     __syncthreads();  // the strip's horizontal taps
-    const uint32_t bi = blockIdx.y * 4u + wave;
+    const uint32_t bi = by * 4u + wave;
     if (bi >= B.n_bands) return;
     const uint32_t yf = B.ya + B.rows * bi;
     const uint32_t ROWS = min(B.rows, B.yb - yf);
@@ -1151,16 +1158,16 @@ hipError_t launch_resize_down(const ResizePlanes &p, int batch, uint32_t dw, uin
 
 template <int A>
 static void launch_resize_poly_a(dim3 grid, size_t lds, hipStream_t s, uint32_t rt, const ResizePlanes &p, uint32_t dw, uint32_t dh,
-                                 TapsDev v, TapsDev h, uint32_t tile_w, uint32_t ncp, const PolyBands &b)
+                                 TapsDev v, TapsDev h, uint32_t tile_w, uint32_t ncp, const PolyBands &b, const XcdOrder &x)
 {
-    if (rt == 2) resize_poly_kernel<A, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
-    else if (rt == 4) resize_poly_kernel<A, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
-    else resize_poly_kernel<A, 8><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
+    if (rt == 2) resize_poly_kernel<A, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b, x);
+    else if (rt == 4) resize_poly_kernel<A, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b, x);
+    else resize_poly_kernel<A, 8><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b, x);
 }
 
 // Rows [reg_a, reg_b) of the vertical table are regular: `ages` x `ratio` taps each, windows `ratio` apart, equal weights.
 hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,
-                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, hipStream_t s)
+                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, bool xcd, hipStream_t s)
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (batch < 1 || batch > 4) return hipErrorInvalidValue;
@@ -1192,9 +1199,13 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     if (!add_tiles(0, b.ya) || !add_tiles(b.yb, dh)) return hipErrorInvalidValue;
     const size_t lds = resize_down_lds_bytes(16, ncp, tile_w, h.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, b.nyb + nt, batch);
-    if (ages == 2) launch_resize_poly_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
-    else if (ages == 4) launch_resize_poly_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
-    else launch_resize_poly_a<6>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
+    // KC_POLY_XCD=0 / 1: never / always (A/B); default: the caller's hint (planes that fit the Infinity Cache)
+    static const int xcd_env = std::getenv("KC_POLY_XCD") ? std::atoi(std::getenv("KC_POLY_XCD")) : -1;
+    const XcdOrder x = xcd_order(grid.x, grid.y, xcd_env < 0 ? xcd : xcd_env != 0);
+    if (x.per) grid = dim3(8u * x.per, 1, batch);
+    if (ages == 2) launch_resize_poly_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
+    else if (ages == 4) launch_resize_poly_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
+    else launch_resize_poly_a<6>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
     return hipGetLastError();
 }
 
@@ -1559,19 +1570,22 @@ static __device__ __forceinline__ void h2n_quad(f4 px, f4 up, f4 left, float pdx
 // h + 1 rows, the band's rows preceded by the row above its first one (the caller's halo: the previous band's last
 // row, or the image's last row for the band that starts at row 0); `full_h` is the height of the whole image, which
 // is what the bitangent's 1 / height means (src/node/height_to_normal.rs:38).
-template <bool BAND, bool NT>  // NT: the three result planes do not fit the Infinity Cache (cache_policy_mask)
+// TILED: a workgroup is 2^tq column quads x 256 / 2^tq rows instead of 256 consecutive quads of one row, and the grid is
+// (column block, row group) with the column block fastest.  Workgroups go to the 8 XCDs in turn (id % 8), so with a multiple of
+// 8 column blocks per row a column block stays on ONE XCD all the way down the image: the row above, which every pixel reads,
+// is in this workgroup or was loaded a moment ago by the same XCD -- an L2 hit instead of a second trip over the fabric for
+// the whole plane (4096^2: 51.0 -> 43.7 us, 0.66 -> 0.77 of the HBM peak; profiles/r03_h2n_tiled_ab.txt).
+template <bool BAND, bool NT, bool TILED>  // NT: the three result planes do not fit the Infinity Cache (cache_policy_mask)
 __global__ __launch_bounds__(256) void height_to_normal_kernel(const float *__restrict__ hgt, uint32_t hpitch,
                                                                uint32_t w, uint32_t h, uint32_t full_h,
                                                                float *__restrict__ nx, float *__restrict__ ny,
-                                                               float *__restrict__ nz, uint32_t opitch)
+                                                               float *__restrict__ nz, uint32_t opitch, uint32_t tq)
 {
     const uint32_t row_units = (w + 3) / 4;
     const uint32_t total = row_units * h;
     const float pdx = 1.0f / (float)w;
     const float pdy = 1.0f / (float)full_h;
-    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-        const uint32_t y = idx / row_units;
-        const uint32_t q = idx - y * row_units;
+    auto pixel_quad = [&](uint32_t y, uint32_t q) {
         const uint32_t yc = BAND ? y + 1 : y;                          // row of this pixel in `hgt`
         const uint32_t yu = BAND ? y : (y == 0 ? h - 1 : y - 1);       // row above it
         const float *rowp = hgt + (size_t)yc * hpitch;
@@ -1584,6 +1598,15 @@ __global__ __launch_bounds__(256) void height_to_normal_kernel(const float *__re
         st_policy<NT>(reinterpret_cast<f4 *>(nx + o), r);
         st_policy<NT>(reinterpret_cast<f4 *>(ny + o), g);
         st_policy<NT>(reinterpret_cast<f4 *>(nz + o), b);
+    };
+    if (TILED) {  // the grid covers the image: one quad per thread
+        const uint32_t q = (blockIdx.x << tq) + (threadIdx.x & ((1u << tq) - 1u)), y = (blockIdx.y << (8u - tq)) + (threadIdx.x >> tq);
+        if (q < row_units && y < h) pixel_quad(y, q);
+    } else {
+        for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+            const uint32_t y = idx / row_units;
+            pixel_quad(y, idx - y * row_units);
+        }
     }
 }
 
@@ -1594,16 +1617,33 @@ hipError_t launch_height_to_normal(const float *hgt, uint32_t hpitch, uint32_t w
     const bool nts = (nt_mask & 0x100u) != 0;  // the height plane is re-read by neighbouring rows: never marked
     const uint64_t total = (uint64_t)((w + 3) / 4) * h;
     if (total == 0) return hipSuccess;
+    const uint32_t row_units = (w + 3) / 4;
+    // Tile width: 128, 64 or 32 quads, the widest that cuts the row into a multiple of 8 column blocks (widths that are
+    // multiples of 4096, 2048 or 1024 pixels), else the widest the row holds -- rows shared inside the workgroup pay even when
+    // the column blocks wander over the XCDs (3000^2: 29.5 -> 26.3 us).  KC_H2N_TILED=0: the plain mapping (A/B).
+    static const int tiled_env = std::getenv("KC_H2N_TILED") ? std::atoi(std::getenv("KC_H2N_TILED")) : -1;
+    uint32_t tq = 0;
+    for (uint32_t t : { 7u, 6u, 5u })
+        if (!tq && row_units % (8u << t) == 0) tq = t;
+    for (uint32_t t : { 7u, 6u, 5u })
+        if (!tq && row_units >= (1u << t)) tq = t;
+    bool tiled = tiled_env != 0 && tq != 0;
+    if (!tq) tq = 7;
+    if ((((uint64_t)h + (256u >> tq) - 1) >> (8u - tq)) >= 65536u) tiled = false;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > grid_cap(1u << 30)) blocks = grid_cap(1u << 30);
-    if (band && nts)
-        height_to_normal_kernel<true, true><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch);
-    else if (band)
-        height_to_normal_kernel<true, false><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch);
-    else if (nts)
-        height_to_normal_kernel<false, true><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, h, nx, ny, nz, opitch);
-    else
-        height_to_normal_kernel<false, false><<<dim3((unsigned)blocks), 256, 0, s>>>(hgt, hpitch, w, h, h, nx, ny, nz, opitch);
+    const dim3 grid = tiled ? dim3((row_units + (1u << tq) - 1u) >> tq, (h + (256u >> tq) - 1u) >> (8u - tq)) : dim3((unsigned)blocks);
+    if (!band) full_h = h;
+#define KC_H2N(BAND, NT)                                                                                                         \
+    do {                                                                                                                         \
+        if (tiled) height_to_normal_kernel<BAND, NT, true><<<grid, 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch, tq);   \
+        else height_to_normal_kernel<BAND, NT, false><<<grid, 256, 0, s>>>(hgt, hpitch, w, h, full_h, nx, ny, nz, opitch, tq);        \
+    } while (0)
+    if (band && nts) KC_H2N(true, true);
+    else if (band) KC_H2N(true, false);
+    else if (nts) KC_H2N(false, true);
+    else KC_H2N(false, false);
+#undef KC_H2N
     return hipGetLastError();
 }
 

@@ -617,6 +617,8 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
             // both axes down-sampled: the wave-private form where its tables exist (down2.hip)
             // ... except where the streaming kernel of integer ratios is the faster one: ratios 4 and 8 (Lanczos3 4096^2 -> 1024^2
             // 23.5 against 26.7 us, CatmullRom 18.1 / 21.4; at ratio 2 down2 wins, 26.3 / 30.4 -- profiles/r03_down2_ab.txt)
+            // tiles in XCD order while source and result stay in the Infinity Cache (the budget of the cache policy)
+            const bool fits_cache = (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height) <= (208ull << 20);
             const bool poly_first = t.poly && tv->host.reg_ratio >= 4;
             if (c.down2 > (poly_first ? 1 : 0) && tv->host.d2_nc && tv->host.d2_vrec_dev && th->host.d2_tile_w &&
                 th->host.d2_hw_dev && th->host.d2_strips_dev) {
@@ -631,8 +633,7 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 a.tile_w = th->host.d2_tile_w;
                 a.dw = size.width;
                 a.dh = size.height;
-                // tiles in XCD order while source and result stay in the Infinity Cache (the budget of the cache policy)
-                a.xcd_per = (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height) <= (208ull << 20) ? 1u : 0u;
+                a.xcd_per = fits_cache ? 1u : 0u;
                 hipError_t e2 = launch_resize_down2(rp, n, a, c.stream);
                 if (e2 != hipSuccess) return hip_fail(e2, "launch_resize_down2");
                 c.launches++;
@@ -641,7 +642,10 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 return KC_OK;
             }
             hipError_t e = t.poly ? launch_resize_poly(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.ncp, tv->host.reg_a,
-                                                       tv->host.reg_b, tv->host.reg_ages, tv->host.reg_ratio, c.stream)
+                                                       tv->host.reg_b, tv->host.reg_ages, tv->host.reg_ratio,
+                                                       // (windows of up to 24 rows: Lanczos3 4:1 23.9 -> 22.3 us, Triangle 8:1 17.2 ->
+                                                       // 16.1; Gaussian 8:1, 48 rows, 30.8 -> 35.1 -- profiles/r03_poly_xcd_ab.txt)
+                                                       fits_cache && tv->host.reg_ages * tv->host.reg_ratio <= 24, c.stream)
                            : t.down ? launch_resize_down(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, c.stream)
                                   : launch_resize_lds(rp, n, size.width, size.height, tv->dev, th->dev, th->host.min_count, t.tile_w,
                                                       t.tile_h, t.ncp, c.stream);
