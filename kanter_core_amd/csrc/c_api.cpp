@@ -79,6 +79,7 @@ try {
     if (const char *rm = std::getenv("KC_RESIZE_MODE")) c.resize_mode = std::atoi(rm);
     if (const char *cp = std::getenv("KC_CACHE_POLICY")) c.cache_policy = std::atoi(cp) != 0;
     if (const char *c1 = std::getenv("KC_CHAIN1")) c.chain1 = std::atoi(c1) != 0;
+    if (const char *j = std::getenv("KC_JOIN")) c.join = std::atoi(j) != 0;
     if (const char *d2 = std::getenv("KC_DOWN2")) c.down2 = std::max(0, std::min(2, std::atoi(d2)));
     if (const char *rt = std::getenv("KC_RESIZE_TILE_H")) c.resize_tile_h = std::atoi(rt);
     if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
@@ -233,6 +234,7 @@ try {
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
     if (std::strcmp(name, "chain1") == 0) ctx().chain1 = value != 0;
     else if (std::strcmp(name, "replay") == 0) ctx().replay = value != 0;
+    else if (std::strcmp(name, "join") == 0) ctx().join = value != 0;
     else if (std::strcmp(name, "down2") == 0 && value >= 0 && value <= 2) ctx().down2 = value;
     else {
         set_error(std::string("unknown option ") + name);
@@ -247,6 +249,7 @@ try {
     KC_ARG(name && value);
     if (std::strcmp(name, "chain1") == 0) *value = ctx().chain1 ? 1 : 0;
     else if (std::strcmp(name, "replay") == 0) *value = ctx().replay ? 1 : 0;
+    else if (std::strcmp(name, "join") == 0) *value = ctx().join ? 1 : 0;
     else if (std::strcmp(name, "down2") == 0) *value = ctx().down2;
     else {
         set_error(std::string("unknown option ") + name);
@@ -337,7 +340,7 @@ try {
     P.row_units = 1;
     for (uint32_t i = 0; i < n_ops; ++i) {
         const uint32_t from = words[i] >> 8;
-        KC_ARG((words[i] & 0xffu) <= CH_MUL_INV && from <= n_in);
+        KC_ARG((words[i] & 0xffu) <= CH_SAVE_LOAD && (from <= n_in || (from == (uint32_t)KC_CHAIN_SRC_SAVED && (words[i] & 0xffu) != CH_SAVE_LOAD)));
         ((i & 1u) ? P.step[0][i / 2].b : P.step[0][i / 2].a).word = words[i];
     }
     if (source && cap) {

@@ -26,10 +26,16 @@ enum ChainCode : unsigned char {
     CH_ADD_INV = 10,   // c - (acc + x)
     CH_SUBL_INV = 11,  // c - (acc - x)
     CH_SUBR_INV = 12,  // c - (x - acc)
-    CH_MUL_INV = 13    // c - (acc * x)
+    CH_MUL_INV = 13,   // c - (acc * x)
+    // Two chains in one program (runtime.cpp, plane_mix: a Mix whose two inputs are BOTH unevaluated chains).  CH_SAVE_LOAD
+    // puts the running value aside and starts the second chain from x; the step that combines the two has the saved value
+    // as its operand (operand source KC_CHAIN_SRC_SAVED).  Only the kernels compiled at run time implement these: the
+    // interpreter never sees such a program (the host runs the second chain on its own instead, runtime.cpp chain_launch).
+    CH_SAVE_LOAD = 14  // saved = acc; acc = x
 };
+enum { KC_CHAIN_SRC_SAVED = 15 };  // operand source (word bits 8-15): the value CH_SAVE_LOAD put aside
 
-// word: bits 0-7 ChainCode, bits 8-15 operand source (0 = the constant c, k + 1 = input plane k).
+// word: bits 0-7 ChainCode, bits 8-15 operand source (0 = the constant c, k + 1 = input plane k, KC_CHAIN_SRC_SAVED).
 struct ChainStepRec {
     unsigned int word;
     float c;

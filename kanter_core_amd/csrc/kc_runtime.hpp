@@ -123,12 +123,15 @@ namespace kc {
 
 struct ChainStep {
     uint8_t code;       // ChainCode
-    kc_plane *operand;  // retained; MEM or CONST
+    kc_plane *operand;  // retained; MEM or CONST -- or, in a link, LAZY: a second chain joined in (plane_mix); in a flat
+                        // Chain that one is expanded and the combining step's operand is saved_value_marker()
 };
+kc_plane *saved_value_marker();
 
 struct Chain : Pooled<Chain> {
     kc_plane *start = nullptr;  // retained; MEM, CONST or RESIZE
     std::vector<ChainStep> steps;
+    std::vector<kc_plane *> joined;  // retained; the LAZY planes whose chains were expanded into `steps` (CH_SAVE_LOAD)
     ~Chain();
 };
 
@@ -141,6 +144,7 @@ struct ChainLink : Pooled<ChainLink> {
     kc_plane *start = nullptr;  // retained; the chain's first value when prev == nullptr
     ChainStep step{};           // operand retained
     uint32_t length = 1;        // steps up to and including this one (an upper bound once a prev was forced)
+    bool joins = false;         // some step up to this one has a LAZY operand (a joined chain)
     int n_in = 0;               // distinct MEM / RESIZE planes the whole chain reads (same bound)
     // Their identities BY VALUE (device pointer + pitch of a resident plane, address of a deferred resize):
     // the planes themselves are kept alive by the links that use them, which may be gone once a prefix
@@ -217,6 +221,7 @@ struct Context {
     bool fusion = true;
     bool replay = true;  // an evaluation that repeats the recorded one is replayed without the walk (kc_set_option("replay", 0); env KC_REPLAY)
     int down2 = 1;       // resize_down2_kernel: 0 off, 1 except where resize_poly_kernel runs at ratio 4 or 8, 2 there too (kc_set_option("down2"); env KC_DOWN2)
+    bool join = true;    // a Mix of two unevaluated chains keeps both in one program (kc_set_option("join", 0); env KC_JOIN)
     bool chain1 = true;  // one-step programs run the ahead-of-time kernels of chain1.hip (kc_set_option("chain1", 0): interpreter / specialiser, A/B and tests)
     int cache_policy = 1;  // 1: launches whose streams exceed the Infinity Cache mark them nontemporal (cache_policy_mask); 0: plain loads / stores (KC_CACHE_POLICY, kc_set_cache_policy)
     int max_blocks = 4096;

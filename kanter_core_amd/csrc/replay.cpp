@@ -160,6 +160,10 @@ int replay_try(kc_live_graph &lg, uint32_t id, bool *hit)
         const uint64_t px4 = 4ull * L.w * L.h;
         P.nt_mask = chain_cache_policy(L.in_refs, P.n_in, px4 * L.batch, px4 * L.batch);
         hipError_t he = chain_dispatch(P, L.batch, L.mode, L.w, L.h, outs[li * KC_CHAIN_MAX_BATCH]->pitch);
+        if (he == hipErrorNotReady) {  // a program that joins two chains, and its kernel is not to be had (kc_set_specialize(0)): walk
+            drop_outs();
+            return KC_OK;
+        }
         if (he != hipSuccess) {
             drop_outs();
             return hip_fail(he, "launch_chain (replay)");

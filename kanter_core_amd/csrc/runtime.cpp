@@ -251,6 +251,20 @@ Chain::~Chain()
 {
     plane_release(start);
     for (auto &s : steps) plane_release(s.operand);
+    for (auto *j : joined) plane_release(j);
+}
+
+// Operand of the step that combines a joined chain's value with the value CH_SAVE_LOAD put aside.  Never freed: its count
+// starts far above anything retain / release can take away.
+kc_plane *saved_value_marker()
+{
+    static kc_plane *m = [] {
+        kc_plane *p = new kc_plane();
+        p->kind = kc_plane::CONST;
+        p->refs = 1 << 30;
+        return p;
+    }();
+    return m;
 }
 
 ChainLink::~ChainLink()
@@ -303,7 +317,9 @@ static int chain_distinct_inputs(const Chain &ch)
     return (int)ins.size();
 }
 
-// Builds p->chain (start + steps in order) from the links; planes forced meanwhile end the walk.
+// Builds p->chain (start + steps in order) from the links; planes forced meanwhile end the walk.  A step whose operand is a
+// chain that has not run (a join, plane_mix) becomes: CH_SAVE_LOAD(that chain's start), that chain's steps, the step itself
+// with the saved value as its operand and the running value on the other side.
 static void chain_flatten(kc_plane *p)
 {
     KC_PROF("chain_flatten");
@@ -313,7 +329,29 @@ static void chain_flatten(kc_plane *p)
     kc_plane *q = p;
     for (;;) {
         ChainLink *L = q->link;
-        c->steps.push_back(L->step);
+        kc_plane *opnd = L->step.operand;
+        if (opnd->kind == kc_plane::LAZY) {
+            chain_flatten(opnd);  // (its own operands are resident or constant: joined chains do not nest)
+            const Chain &sub = *opnd->chain;
+            // collected back to front: the combining step, the joined chain's steps, its start
+            uint8_t code = L->step.code;  // written for "acc op operand"; the operand's value is now the running one
+            switch (code) {
+            case CH_SUB_L: code = CH_SUB_R; break;
+            case CH_SUB_R: code = CH_SUB_L; break;
+            case CH_DIV_L: code = CH_DIV_R; break;
+            case CH_DIV_R: code = CH_DIV_L; break;
+            case CH_POW_L: code = CH_POW_R; break;
+            case CH_POW_R: code = CH_POW_L; break;
+            default: break;  // + and * commute (ADD_R / MUL_R are canonicalised by chain_fill)
+            }
+            c->steps.push_back({ code, saved_value_marker() });
+            for (size_t i = sub.steps.size(); i-- > 0;) c->steps.push_back(sub.steps[i]);
+            c->steps.push_back({ (uint8_t)CH_SAVE_LOAD, sub.start });
+            c->joined.push_back(opnd);
+            plane_retain(opnd);
+        } else {
+            c->steps.push_back(L->step);
+        }
         if (L->prev && L->prev->kind == kc_plane::LAZY) {
             q = L->prev;
             continue;
@@ -348,6 +386,7 @@ struct BuiltChain {
     uint32_t in_refs[KC_CHAIN_MAX_IN] = { 0, 0, 0, 0 };  // reference counts of channel 0's resident inputs when the program was built
     int mode = 0;  // 0 = {+,-,*}, 1 = + divide, 2 = + pow
     kc_plane *sampled[KC_CHAIN_MAX_BATCH] = { nullptr, nullptr, nullptr, nullptr };  // RESIZE operand per channel
+    bool joins = false;  // the program holds CH_SAVE_LOAD: only its own compiled kernel can run it
 };
 
 static int input_index(std::vector<const kc_plane *> &ins, const kc_plane *p)
@@ -376,6 +415,7 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
     for (auto &st : ch.steps)
         if (st.operand->kind == kc_plane::MEM) input_index(ins, st.operand);
     auto slot = [&](kc_plane *q, float *c) -> int {
+        if (q == saved_value_marker()) return KC_CHAIN_SRC_SAVED - 1;
         if (q->kind == kc_plane::MEM) return input_index(ins, q);
         if (q->kind == kc_plane::RESIZE) {
             samp = q;
@@ -405,8 +445,9 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
         uint8_t code = st.code;
         if (code == CH_ADD_R) code = CH_ADD;  // commutative: the same IEEE result
         if (code == CH_MUL_R) code = CH_MUL;
+        if (code == CH_SAVE_LOAD) bc.joins = true;
         if (src >= 0 && code <= CH_MUL && i + 1 < ch.steps.size() && ch.steps[i + 1].code == CH_SUB_R &&
-            ch.steps[i + 1].operand->kind == kc_plane::CONST) {
+            ch.steps[i + 1].operand->kind == kc_plane::CONST && ch.steps[i + 1].operand != saved_value_marker()) {
             static const uint8_t inv[4] = { CH_ADD_INV, CH_SUBL_INV, CH_SUBR_INV, CH_MUL_INV };
             code = inv[code];
             c = ch.steps[i + 1].operand->cval;
@@ -567,12 +608,19 @@ hipError_t chain_dispatch(ChainProgram &P, int batch, int mode, uint32_t w, uint
     if (!launched) {
         // a program-specialised straight-line kernel if one has been compiled (specialize.cpp) ...
         hipError_t e = launch_chain_specialized(P, batch, c.stream, &launched);
-        // ... otherwise the interpreter
-        if (e == hipSuccess && !launched) e = launch_chain(P, batch, mode, c.max_blocks, c.chain_unroll, c.stream);
+        // ... otherwise the interpreter -- which does not know the codes of a program that joins two chains (chain_launch
+        // never sends it one; a replay of such a launch after kc_set_specialize(0) can)
+        if (e == hipSuccess && !launched) {
+            for (uint32_t i = 0; i < P.n_ops; ++i)
+                if ((((i & 1u) ? P.step[0][i / 2].b.word : P.step[0][i / 2].a.word) & 0xffu) == CH_SAVE_LOAD) return hipErrorNotReady;
+            e = launch_chain(P, batch, mode, c.max_blocks, c.chain_unroll, c.stream);
+        }
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
+
+static int chain_flatten_to_fit(kc_plane *p);
 
 static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 {
@@ -609,10 +657,29 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
     }
     if (!launched) {
         hipError_t e = chain_dispatch(P, batch, bc.mode, p0->w, p0->h, outs[0]->pitch);
+        if (e == hipErrorNotReady && bc.joins) {
+            // The program joins two chains and its kernel has not been compiled (yet): the joined chains run on their own,
+            // as they did before joins existed, and the caller rebuilds the program around their results.
+            for (auto *o : outs) plane_release(o);
+            std::vector<kc_plane *> subs;
+            for (int b = 0; b < batch; ++b)
+                for (auto *j : planes[b]->chain->joined) subs.push_back(j);
+            KC_TRY(planes_force(subs.data(), (int)subs.size()));
+            for (int b = 0; b < batch; ++b) {
+                if (planes[b]->kind != kc_plane::LAZY) continue;  // ran as one of the joined chains' inputs (planes_force skips it)
+                delete planes[b]->chain;
+                planes[b]->chain = nullptr;
+                KC_TRY(chain_flatten_to_fit(planes[b]));
+            }
+            c.counters["join_fallbacks"]++;
+            if (c.capture) c.capture->ok = false;  // not what this evaluation will do once the kernel is there: do not record it
+            return KC_RETRY_CHAIN;
+        }
         if (e != hipSuccess) {
             for (auto *o : outs) plane_release(o);
             return hip_fail(e, "launch_chain");
         }
+        if (bc.joins) c.counters["join_launches"]++;
     }
     c.launches++;
     {
@@ -661,6 +728,26 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
     return KC_OK;
 }
 
+// Flattens p's chain.  The input count was bounded when the chain was built, but a constant operand can have been
+// materialised since (kc_plane_materialize, a resize of it ...) and now occupies an input slot, and joined chains that had to
+// run on their own (chain_launch) each became one.  Then the prefix is run on its own and the chain restarts from its result.
+static int chain_flatten_to_fit(kc_plane *p)
+{
+    chain_flatten(p);
+    while (chain_distinct_inputs(*p->chain) > KC_CHAIN_MAX_IN) {
+        kc_plane *prev = p->link->prev;
+        if (!prev || prev->kind != kc_plane::LAZY) {
+            set_error("chain with more than KC_CHAIN_MAX_IN inputs cannot be split");
+            return KC_ERR_UNSUPPORTED;
+        }
+        KC_TRY(plane_force(prev));
+        delete p->chain;
+        p->chain = nullptr;
+        chain_flatten(p);
+    }
+    return KC_OK;
+}
+
 int planes_force(kc_plane *const *planes, int n)
 {
     KC_PROF("planes_force");
@@ -681,26 +768,18 @@ int planes_force(kc_plane *const *planes, int n)
         // forcing a prefix or an operand below can run another plane of this very list (an image may hold a chain and
         // its own prefix): it is resident then and has nothing left to flatten
         if (p->kind != kc_plane::LAZY) continue;
-        chain_flatten(p);
-        // The input count was bounded when the chain was built, but a constant operand can have been
-        // materialised since (kc_plane_materialize, a resize of it ...) and now occupies an input slot.
-        // Then the prefix is run on its own and the chain restarts from its result.
-        while (chain_distinct_inputs(*p->chain) > KC_CHAIN_MAX_IN) {
-            kc_plane *prev = p->link->prev;
-            if (!prev || prev->kind != kc_plane::LAZY) {
-                set_error("chain with more than KC_CHAIN_MAX_IN inputs cannot be split");
-                return KC_ERR_UNSUPPORTED;
-            }
-            KC_TRY(plane_force(prev));
-            delete p->chain;
-            p->chain = nullptr;
-            chain_flatten(p);
-        }
+        KC_TRY(chain_flatten_to_fit(p));
         KC_TRY(chain_prepare(p));
     }
     todo.erase(std::remove_if(todo.begin(), todo.end(), [](kc_plane *q) { return q->kind != kc_plane::LAZY; }), todo.end());
     size_t i = 0;
     while (i < todo.size()) {
+        // (a launch further up may have had to run this plane first: a joined chain's fallback, a split prefix)
+        if (todo[i]->kind != kc_plane::LAZY) {
+            ++i;
+            continue;
+        }
+        if (!todo[i]->chain) KC_TRY(chain_flatten_to_fit(todo[i]));
         BuiltChain bc;
         kc_plane *group[KC_CHAIN_MAX_BATCH];
         int batch = 0;
@@ -710,8 +789,8 @@ int planes_force(kc_plane *const *planes, int n)
         }
         group[batch++] = todo[i];
         size_t j = i + 1;
-        while (j < todo.size() && batch < KC_CHAIN_MAX_BATCH && todo[j]->w == todo[i]->w &&
-               todo[j]->h == todo[i]->h && chain_fill(bc, batch, todo[j])) {
+        while (j < todo.size() && batch < KC_CHAIN_MAX_BATCH && todo[j]->kind == kc_plane::LAZY && todo[j]->chain &&
+               todo[j]->w == todo[i]->w && todo[j]->h == todo[i]->h && chain_fill(bc, batch, todo[j])) {
             group[batch++] = todo[j];
             ++j;
         }
@@ -792,6 +871,38 @@ static kc_plane *lazy_pair_victim(kc_plane *l, kc_plane *r)
     return (l != r && l->link->length >= r->link->length) ? r : l;
 }
 
+// Both inputs of a Mix are chains that have not run.  One of them used to be run on the spot -- a plane written and read
+// again, a launch -- because a program has one running value.  With one more register it need not be: the longer chain goes on
+// (`acc`), the shorter one is kept as the step's operand and evaluated INSIDE the same program (CH_SAVE_LOAD, chain_flatten).
+// BASELINE config #4's add tree over eight branches: 9 launches and 33 plane passes per channel become 5 and 25.
+// Conditions: the shorter chain is plain (no join of its own, no resampled operand), the two together fit one program, and
+// the longer one has room for the shorter one's RESULT as an input, which is what it becomes whenever the program's own kernel
+// is not available (chain_launch).
+static bool join_ok(const kc_plane *acc, const kc_plane *sub)
+{
+    Context &c = ctx();
+    if (!c.join || !c.fusion || acc == sub || specialize_get_mode() == 0) return false;
+    const ChainLink &A = *acc->link, &B = *sub->link;
+    if (B.joins || A.n_in > KC_CHAIN_MAX_IN - 1 || B.n_in > KC_CHAIN_MAX_IN) return false;
+    if (A.length + B.length + 2u > (uint32_t)KC_CHAIN_MAX_OPS) return false;
+    ChainLink probe;
+    probe.n_in = A.n_in;
+    for (int i = 0; i < A.n_in; ++i) {
+        if (A.ins[i].q == ~(size_t)0) return false;  // a resampled operand: the fused resize + chain kernels keep their programs plain
+        probe.ins[i] = A.ins[i];
+    }
+    for (int i = 0; i < B.n_in; ++i) {
+        if (B.ins[i].q == ~(size_t)0) return false;
+        bool seen = false;
+        for (int k = 0; k < probe.n_in && k <= KC_CHAIN_MAX_IN; ++k) seen |= probe.ins[k] == B.ins[i];
+        if (!seen) {
+            if (probe.n_in >= KC_CHAIN_MAX_IN) return false;
+            probe.ins[probe.n_in++] = B.ins[i];
+        }
+    }
+    return true;
+}
+
 // The planes plane_mix(l[c], r[c]) would have to run before it can extend a chain, forced TOGETHER: the R, G
 // and B chains of an RGBA operand share one program and leave as one launch (blockIdx.y) instead of three.
 int planes_mix_prepare(kc_plane *const *ls, kc_plane *const *rs, int n)
@@ -799,10 +910,14 @@ int planes_mix_prepare(kc_plane *const *ls, kc_plane *const *rs, int n)
     std::lock_guard<std::recursive_mutex> lk(ctx().mu);
     std::vector<kc_plane *> todo;
     for (int c = 0; c < n; ++c)
-        if (ls[c]->kind == kc_plane::LAZY && rs[c]->kind == kc_plane::LAZY) todo.push_back(lazy_pair_victim(ls[c], rs[c]));
+        if (ls[c]->kind == kc_plane::LAZY && rs[c]->kind == kc_plane::LAZY) {
+            kc_plane *sub = lazy_pair_victim(ls[c], rs[c]);
+            if (!join_ok(sub == ls[c] ? rs[c] : ls[c], sub)) todo.push_back(sub);
+        }
     if (!todo.empty()) KC_TRY(planes_force(todo.data(), (int)todo.size()));
     todo.clear();
     for (int c = 0; c < n; ++c) {
+        if (ls[c]->kind == kc_plane::LAZY && rs[c]->kind == kc_plane::LAZY) continue;  // a join (join_ok has checked the room)
         kc_plane *acc = ls[c]->kind == kc_plane::LAZY ? ls[c] : rs[c]->kind == kc_plane::LAZY ? rs[c] : nullptr;
         if (acc && chain_full_with(acc, acc == ls[c] ? rs[c] : ls[c])) todo.push_back(acc);
     }
@@ -833,8 +948,18 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
     // Pick the running value: a lazy operand is continued, the other side becomes the step operand.
     kc_plane *acc = nullptr, *opnd = nullptr;
     bool acc_is_left = true;
-    if (l->kind == kc_plane::LAZY && r->kind == kc_plane::LAZY) KC_TRY(plane_force(lazy_pair_victim(l, r)));  // keep the longer chain lazy
-    if (l->kind == kc_plane::LAZY) {
+    bool join = false;
+    if (l->kind == kc_plane::LAZY && r->kind == kc_plane::LAZY) {
+        kc_plane *sub = lazy_pair_victim(l, r);  // keep the longer chain lazy
+        if (join_ok(sub == l ? r : l, sub)) join = true;
+        else KC_TRY(plane_force(sub));
+    }
+    if (join) {
+        kc_plane *sub = lazy_pair_victim(l, r);
+        acc = sub == l ? r : l;
+        opnd = sub;
+        acc_is_left = acc == l;
+    } else if (l->kind == kc_plane::LAZY) {
         acc = l;
         opnd = r;
         acc_is_left = true;
@@ -844,7 +969,7 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
         acc_is_left = false;
     }
     // A chain that is full (steps or distinct inputs) is run first and restarted from its result.
-    if (acc && chain_full_with(acc, opnd)) {
+    if (acc && !join && chain_full_with(acc, opnd)) {
         KC_TRY(plane_force(acc));
         acc = nullptr;
     }
@@ -852,14 +977,27 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
     if (acc) {
         L->n_in = acc->link->n_in;
         for (int i = 0; i < L->n_in && i <= KC_CHAIN_MAX_IN; ++i) L->ins[i] = acc->link->ins[i];
-        link_add_input(*L, opnd);
+        if (join) {
+            const ChainLink &B = *opnd->link;
+            for (int i = 0; i < B.n_in && i <= KC_CHAIN_MAX_IN; ++i) {
+                bool seen = false;
+                for (int k = 0; k < L->n_in && k <= KC_CHAIN_MAX_IN; ++k) seen |= L->ins[k] == B.ins[i];
+                if (!seen) {
+                    if (L->n_in <= KC_CHAIN_MAX_IN) L->ins[L->n_in] = B.ins[i];
+                    L->n_in++;
+                }
+            }
+        } else {
+            link_add_input(*L, opnd);
+        }
     }
     if (acc) {
         L->prev = acc;
         plane_retain(acc);
         L->step = { code_for(mix, acc_is_left), opnd };
         plane_retain(opnd);
-        L->length = acc->link->length + 1;
+        L->length = acc->link->length + (join ? opnd->link->length + 2u : 1u);
+        L->joins = acc->link->joins || join;
     } else {
         L->prev = nullptr;
         L->start = l;

@@ -236,6 +236,9 @@ def test_an_evaluation_of_several_launches_is_replayed(kc, orc, n_branches, sub_
     h, w = 24, 72
     sources = [(synthetic_rgba(SEED_A + k, h, w), synthetic_rgba(SEED_B + k, h, w)) for k in range(n_branches)]
     want = fanin_oracle(orc, sources, sub_nodes)
+    # programs that join two chains (tests/test_gpu_join.py) are compiled at first sight here: while such a kernel is still
+    # being compiled an evaluation falls back to separate launches and is deliberately not recorded
+    kc.set_specialize(2)
     kc.set_option("replay", 1)
     tp1, lg1, plugs1, root1 = fanin_live(kc, sources, sub_nodes)
     kc.set_option("replay", 0)
@@ -261,7 +264,7 @@ def test_an_evaluation_of_several_launches_is_replayed(kc, orc, n_branches, sub_
     kc.set_option("replay", 1)
     assert kc.stats_counter("replayed_evaluations") - n0 >= 3
     assert len(set(launches[1:])) == 1 and launches[1] >= 1, launches  # a replay issues the launches the walk issued
-    if n_branches > 1:
+    if n_branches > 2:  # (two short branches and their Mix are ONE launch once the program that joins them has its kernel)
         assert launches[1] > 1
     # only SOME branches are re-plugged: another starting point, so the walk runs (and is recorded in its turn)
     kc.set_option("replay", 1)
@@ -281,3 +284,4 @@ def test_an_evaluation_of_several_launches_is_replayed(kc, orc, n_branches, sub_
             lg1.connect(na, first, 0, 0)
         got = lg1.await_clean(root1).slot_data(root1, 0).image.planes()
         assert_planes(got, want, what="another source, evaluation %d" % rep)
+    kc.set_specialize(1)

@@ -7,6 +7,8 @@ import kanter_core_amd as kc
 
 ADD, SUB_L, SUB_R, MUL, DIV_L, DIV_R, POW_L, POW_R = range(8)
 ADD_INV, SUBL_INV, SUBR_INV, MUL_INV = 10, 11, 12, 13
+SAVE_LOAD = 14  # saved = acc; acc = x: a second chain inside the program (csrc/chain_program.h)
+SAVED = 14      # operand source index of the saved value (word bits 8-15 = 15)
 
 
 def word(code, src):
@@ -35,6 +37,17 @@ def test_every_step_code_compiles(flat):
     assert ("idx / P.row_units" in src) == (not flat)
 
 
+def test_a_program_that_joins_two_chains():
+    """(in0 + in1) * c, then a second chain in2 - in3 inside the same program, then first - second; then the usual invert.
+    What config #4's Mix(Add) tree of two unevaluated branches becomes (csrc/runtime.cpp plane_mix / chain_flatten)."""
+    words = [word(ADD, 1), word(MUL, -1), word(SAVE_LOAD, 2), word(SUB_L, 3), word(SUBR_INV, SAVED), word(SAVE_LOAD, -1), word(MUL, SAVED)]
+    src = kc.specialize_compile_check(words, n_in=4, start_src=0, flat=True)
+    body = src[src.index('extern "C"'):]
+    assert "acc = (saved = acc, in2);" in body and "acc = acc - in3;" in body
+    assert "pp[2].a.c - (saved - acc)" in body  # saved (first chain) - acc (second chain), then c - that
+    assert "acc = (saved = acc, f4{ pp[2].b.c" in body and "acc = acc * saved;" in body
+
+
 def test_constant_start_and_zero_inputs():
     src = kc.specialize_compile_check([word(MUL, -1), word(SUB_R, -1)], n_in=0, start_src=-1)
     assert "P.start_c[b]" in src
@@ -44,7 +57,9 @@ def test_invalid_programs_are_refused():
     with pytest.raises(kc.TexProError):
         kc.specialize_compile_check([word(ADD, 2)], n_in=2)      # operand slot out of range
     with pytest.raises(kc.TexProError):
-        kc.specialize_compile_check([word(14, 0)], n_in=1)       # unknown code
+        kc.specialize_compile_check([word(15, 0)], n_in=1)       # unknown code
+    with pytest.raises(kc.TexProError):
+        kc.specialize_compile_check([word(SAVE_LOAD, SAVED)], n_in=1)  # a second chain cannot start from the saved value
     with pytest.raises(kc.TexProError):
         kc.specialize_compile_check([word(ADD, 0)], n_in=1, start_src=1)
 
