@@ -316,7 +316,9 @@ def main():
         n_tree = n_branches - 1
         node_px = float(len(mine) * sub_nodes + (n_tree if rank == ev.plan.home else 0)) * S * S
         # per rank: its fused subgraphs (36 B/px each); home: the add tree over 8 resident RGB results -- 4 launches reading
-        # 2, 2, 3, 4 planes and writing 1 each, per channel (chains are linear and hold at most 4 distinct input planes)
+        # 2, 2, 3, 4 planes and writing 1 each, per channel.  An upper bound only: what the launches really move is decided
+        # at run time (on one rank, pairs of branches and their Mix(Add) share a program: 5 launches, 25 plane passes per
+        # channel) and is what the library counts -- the roofline below uses that count (algorithmic_bytes_per_step).
         alg_bytes = len(mine) * 36.0 * S * S + ((15 * 3 * 4.0 * S * S) if rank == ev.plan.home else 0.0)
         kernel = "chain_kernel<2,*> per subgraph + RCCL send/recv + chain_kernel<2..4,*> add tree"
         desc = ("8 independent 16-node subgraphs at %dx%d f32x4 placed by kc_live_graph_partition (%s), branch results sent to "
