@@ -735,6 +735,21 @@ static int chain_flatten_to_fit(kc_plane *p)
 {
     chain_flatten(p);
     while (chain_distinct_inputs(*p->chain) > KC_CHAIN_MAX_IN) {
+        if (!p->chain->joined.empty()) {
+            // Joined chains bring their own inputs along.  The bound plane_mix checked (join_ok) held for the chains as they
+            // were then; a prefix that has been run since counts as ONE new input beside them.  Run the joined chains: each
+            // becomes one input.
+            std::vector<kc_plane *> subs(p->chain->joined);
+            for (auto *q : subs) plane_retain(q);
+            const int fs = planes_force(subs.data(), (int)subs.size());
+            for (auto *q : subs) plane_release(q);
+            KC_TRY(fs);
+            if (p->kind != kc_plane::LAZY) return KC_OK;  // (ran as an input of one of them)
+            delete p->chain;
+            p->chain = nullptr;
+            chain_flatten(p);
+            continue;
+        }
         kc_plane *prev = p->link->prev;
         if (!prev || prev->kind != kc_plane::LAZY) {
             set_error("chain with more than KC_CHAIN_MAX_IN inputs cannot be split");
@@ -769,6 +784,7 @@ int planes_force(kc_plane *const *planes, int n)
         // its own prefix): it is resident then and has nothing left to flatten
         if (p->kind != kc_plane::LAZY) continue;
         KC_TRY(chain_flatten_to_fit(p));
+        if (p->kind != kc_plane::LAZY) continue;
         KC_TRY(chain_prepare(p));
     }
     todo.erase(std::remove_if(todo.begin(), todo.end(), [](kc_plane *q) { return q->kind != kc_plane::LAZY; }), todo.end());
@@ -779,7 +795,10 @@ int planes_force(kc_plane *const *planes, int n)
             ++i;
             continue;
         }
-        if (!todo[i]->chain) KC_TRY(chain_flatten_to_fit(todo[i]));
+        if (!todo[i]->chain) {
+            KC_TRY(chain_flatten_to_fit(todo[i]));
+            if (todo[i]->kind != kc_plane::LAZY) continue;
+        }
         BuiltChain bc;
         kc_plane *group[KC_CHAIN_MAX_BATCH];
         int batch = 0;

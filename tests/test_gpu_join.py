@@ -142,3 +142,58 @@ def test_join_then_replay(kc, orc):
             assert_planes(got, want, what="after kc_set_specialize(0), evaluation %d" % rep)
     finally:
         kc.set_specialize(1)
+
+
+def _braided_graph(kc, seed):
+    """A run of Mix nodes in which every node continues the previous result and takes ANY earlier result, source or constant as
+    its other input (profiles/soak_replay.py's build_simple): chains meet their own prefixes and each other all the time."""
+    rng = np.random.default_rng(seed)
+    tp = kc.TextureProcessor.new()
+    lg = tp.new_live_graph()
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+    outs = []
+    for eid in range(int(rng.integers(1, 4))):
+        planes = [(rng.random((h, w), dtype=np.float32) * np.float32(1.6) - np.float32(0.3)).astype(np.float32) for _ in range(4)]
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(planes)), eid)
+        outs.append(lg.add_node(kc.Node.new(kc.NodeType.Embed(eid))))
+    for _ in range(int(rng.integers(1, 3))):
+        v = lg.add_node(kc.Node.new(kc.NodeType.Value(float(np.float32(rng.random())))))
+        c = lg.add_node(kc.Node.new(kc.NodeType.CombineRgba))
+        for s_ in range(3):
+            lg.connect(v, c, 0, s_)
+        outs.append(c)
+    prev = outs[0]
+    ops = ["Add", "Subtract", "Multiply", "Divide"]
+    for _ in range(int(rng.integers(2, 24))):
+        n = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.parse(ops[rng.integers(len(ops))]))))
+        other = outs[rng.integers(len(outs))]
+        if rng.random() < 0.5:
+            lg.connect(prev, n, 0, 0)
+            lg.connect(other, n, 0, 1)
+        else:
+            lg.connect(other, n, 0, 0)
+            lg.connect(prev, n, 0, 1)
+        prev = n
+        outs.append(n)
+    return tp, lg, prev
+
+
+@pytest.mark.parametrize("seed", [1588953026] + list(range(7100, 7160)))
+def test_braided_graphs_join_fallback_and_plain_agree(kc, seed):
+    """Three ways to the same planes: joins with their kernels (mode 2), joins whose kernels are not there yet (mode 1, first
+    sighting: the joined chains run on their own) and no joins.  Seed 1588953026 (profiles/soak_replay.py): a joined chain
+    brought four inputs along, the chain it joined had been run meanwhile and counted as a fifth -- "cannot be split"."""
+    results = []
+    try:
+        for mode, join in ((1, 1), (2, 1), (2, 0)):
+            kc.set_specialize(mode)
+            kc.set_option("join", join)
+            kc.set_option("replay", 0)
+            tp, lg, last = _braided_graph(kc, seed)
+            results.append(lg.await_clean(last).slot_data(last, 0).image.planes())
+    finally:
+        kc.set_specialize(1)
+        kc.set_option("join", 1)
+        kc.set_option("replay", 1)
+    assert_planes(results[0], results[2], what="first sighting (fallback) vs no joins, seed %d" % seed)
+    assert_planes(results[1], results[2], what="joined kernels vs no joins, seed %d" % seed)
