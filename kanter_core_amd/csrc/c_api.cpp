@@ -339,8 +339,9 @@ try {
     P.rows = flat ? 1u : 2u;
     P.row_units = 1;
     for (uint32_t i = 0; i < n_ops; ++i) {
-        const uint32_t from = words[i] >> 8;
+        const uint32_t from = (words[i] >> 8) & 0xffu, level = words[i] >> 16;
         KC_ARG((words[i] & 0xffu) <= CH_SAVE_LOAD && (from <= n_in || (from == (uint32_t)KC_CHAIN_SRC_SAVED && (words[i] & 0xffu) != CH_SAVE_LOAD)));
+        KC_ARG(level < (uint32_t)KC_CHAIN_MAX_SAVED && (level == 0 || from == (uint32_t)KC_CHAIN_SRC_SAVED || (words[i] & 0xffu) == CH_SAVE_LOAD));
         ((i & 1u) ? P.step[0][i / 2].b : P.step[0][i / 2].a).word = words[i];
     }
     if (source && cap) {

@@ -31,11 +31,14 @@ enum ChainCode : unsigned char {
     // puts the running value aside and starts the second chain from x; the step that combines the two has the saved value
     // as its operand (operand source KC_CHAIN_SRC_SAVED).  Only the kernels compiled at run time implement these: the
     // interpreter never sees such a program (the host runs the second chain on its own instead, runtime.cpp chain_launch).
-    CH_SAVE_LOAD = 14  // saved = acc; acc = x
+    CH_SAVE_LOAD = 14  // saved[level] = acc; acc = x
 };
-enum { KC_CHAIN_SRC_SAVED = 15 };  // operand source (word bits 8-15): the value CH_SAVE_LOAD put aside
+// Operand source (word bits 8-15) KC_CHAIN_SRC_SAVED: the value CH_SAVE_LOAD put aside.  A joined chain can hold joins of its
+// own: KC_CHAIN_MAX_SAVED values can be aside at once, word bits 16-17 say which one a CH_SAVE_LOAD writes / a step reads.
+enum { KC_CHAIN_SRC_SAVED = 15, KC_CHAIN_MAX_SAVED = 3 };
 
-// word: bits 0-7 ChainCode, bits 8-15 operand source (0 = the constant c, k + 1 = input plane k, KC_CHAIN_SRC_SAVED).
+// word: bits 0-7 ChainCode, bits 8-15 operand source (0 = the constant c, k + 1 = input plane k, KC_CHAIN_SRC_SAVED), bits 16-17
+// the saved value meant (CH_SAVE_LOAD, KC_CHAIN_SRC_SAVED).
 struct ChainStepRec {
     unsigned int word;
     float c;

@@ -125,6 +125,7 @@ struct ChainStep {
     uint8_t code;       // ChainCode
     kc_plane *operand;  // retained; MEM or CONST -- or, in a link, LAZY: a second chain joined in (plane_mix); in a flat
                         // Chain that one is expanded and the combining step's operand is saved_value_marker()
+    uint8_t level = 0;  // flat Chain only: which saved value a CH_SAVE_LOAD writes / a step on saved_value_marker() reads
 };
 kc_plane *saved_value_marker();
 
@@ -144,7 +145,7 @@ struct ChainLink : Pooled<ChainLink> {
     kc_plane *start = nullptr;  // retained; the chain's first value when prev == nullptr
     ChainStep step{};           // operand retained
     uint32_t length = 1;        // steps up to and including this one (an upper bound once a prev was forced)
-    bool joins = false;         // some step up to this one has a LAZY operand (a joined chain)
+    uint8_t saved = 0;          // saved values the chain needs at once: 0 = no joined chain, 1 = joins of plain chains, ...
     int n_in = 0;               // distinct MEM / RESIZE planes the whole chain reads (same bound)
     // Their identities BY VALUE (device pointer + pitch of a resident plane, address of a deferred resize):
     // the planes themselves are kept alive by the links that use them, which may be gone once a prefix

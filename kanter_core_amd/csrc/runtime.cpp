@@ -331,7 +331,7 @@ static void chain_flatten(kc_plane *p)
         ChainLink *L = q->link;
         kc_plane *opnd = L->step.operand;
         if (opnd->kind == kc_plane::LAZY) {
-            chain_flatten(opnd);  // (its own operands are resident or constant: joined chains do not nest)
+            chain_flatten(opnd);  // (may hold joins of its own)
             const Chain &sub = *opnd->chain;
             // collected back to front: the combining step, the joined chain's steps, its start
             uint8_t code = L->step.code;  // written for "acc op operand"; the operand's value is now the running one
@@ -344,9 +344,14 @@ static void chain_flatten(kc_plane *p)
             case CH_POW_R: code = CH_POW_L; break;
             default: break;  // + and * commute (ADD_R / MUL_R are canonicalised by chain_fill)
             }
-            c->steps.push_back({ code, saved_value_marker() });
-            for (size_t i = sub.steps.size(); i-- > 0;) c->steps.push_back(sub.steps[i]);
-            c->steps.push_back({ (uint8_t)CH_SAVE_LOAD, sub.start });
+            c->steps.push_back({ code, saved_value_marker(), 0 });
+            for (size_t i = sub.steps.size(); i-- > 0;) {
+                ChainStep st = sub.steps[i];
+                // the joined chain's own joins happen while this one's saved value is aside: one level up
+                if (st.code == CH_SAVE_LOAD || st.operand == saved_value_marker()) st.level++;
+                c->steps.push_back(st);
+            }
+            c->steps.push_back({ (uint8_t)CH_SAVE_LOAD, sub.start, 0 });
             c->joined.push_back(opnd);
             plane_retain(opnd);
         } else {
@@ -453,7 +458,8 @@ static bool chain_fill(BuiltChain &bc, int b, const kc_plane *p)
             c = ch.steps[i + 1].operand->cval;
             ++i;
         }
-        const uint32_t word = chain_op_word(code, src);
+        uint32_t word = chain_op_word(code, src);
+        if (st.code == CH_SAVE_LOAD || st.operand == saved_value_marker()) word |= (uint32_t)st.level << 16;
         auto rec = [&](int ch_) -> ChainStepRec & { return (r & 1) ? P.step[ch_][r / 2].b : P.step[ch_][r / 2].a; };
         if (b == 0) {
             rec(0).word = word;
@@ -894,7 +900,8 @@ static kc_plane *lazy_pair_victim(kc_plane *l, kc_plane *r)
 // again, a launch -- because a program has one running value.  With one more register it need not be: the longer chain goes on
 // (`acc`), the shorter one is kept as the step's operand and evaluated INSIDE the same program (CH_SAVE_LOAD, chain_flatten).
 // BASELINE config #4's add tree over eight branches: 9 launches and 33 plane passes per channel become 5 and 25.
-// Conditions: the shorter chain is plain (no join of its own, no resampled operand), the two together fit one program, and
+// Conditions: no resampled operand on either side, the saved values needed at once fit (KC_CHAIN_MAX_SAVED: the shorter
+// chain may hold joins of its own), the two together fit one program, and
 // the longer one has room for the shorter one's RESULT as an input, which is what it becomes whenever the program's own kernel
 // is not available (chain_launch).
 static bool join_ok(const kc_plane *acc, const kc_plane *sub)
@@ -902,7 +909,7 @@ static bool join_ok(const kc_plane *acc, const kc_plane *sub)
     Context &c = ctx();
     if (!c.join || !c.fusion || acc == sub || specialize_get_mode() == 0) return false;
     const ChainLink &A = *acc->link, &B = *sub->link;
-    if (B.joins || A.n_in > KC_CHAIN_MAX_IN - 1 || B.n_in > KC_CHAIN_MAX_IN) return false;
+    if (std::max<int>(A.saved, B.saved + 1) > KC_CHAIN_MAX_SAVED || A.n_in > KC_CHAIN_MAX_IN - 1 || B.n_in > KC_CHAIN_MAX_IN) return false;
     if (A.length + B.length + 2u > (uint32_t)KC_CHAIN_MAX_OPS) return false;
     ChainLink probe;
     probe.n_in = A.n_in;
@@ -1016,7 +1023,7 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
         L->step = { code_for(mix, acc_is_left), opnd };
         plane_retain(opnd);
         L->length = acc->link->length + (join ? opnd->link->length + 2u : 1u);
-        L->joins = acc->link->joins || join;
+        L->saved = join ? (uint8_t)std::max<int>(acc->link->saved, opnd->link->saved + 1) : acc->link->saved;
     } else {
         L->prev = nullptr;
         L->start = l;

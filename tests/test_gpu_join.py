@@ -81,6 +81,33 @@ def test_four_inputs_two_chains_one_launch(kc, orc):
     assert_planes(got, [want], what="(a * b) - (c + d) in one launch")
 
 
+def test_a_tree_over_four_chains_on_two_sources_is_one_launch(kc, orc):
+    """((a*b - a) + (b*b + a)) / ((a - b)*a - (b + a)*b): seven chains, every Mix above the leaves joins two of them, the top one
+    two chains that hold joins themselves -- two sources, so everything fits one program: one launch."""
+    h, w = 37, 53
+    a, b = gray(SEED_A, 40, h, w), gray(SEED_B, 41, h, w)
+    mk = lambda p: kc.SlotImage.from_planes([p])  # noqa: E731
+    M = lambda o, l, r: kc.mix_process(l, r, getattr(kc.MixType, o))  # noqa: E731
+    O = orc.mix_plane
+    want = O("Divide", O("Add", O("Subtract", O("Multiply", a, b), a), O("Add", O("Multiply", b, b), a)),
+             O("Subtract", O("Multiply", O("Subtract", a, b), a), O("Multiply", O("Add", b, a), b)))
+    kc.set_specialize(2)
+    got = {}
+    for join in (1, 0):
+        kc.set_option("join", join)
+        ia, ib = mk(a), mk(b)
+        ia.materialize(), ib.materialize()
+        l0 = kc.stats()["kernel_launches"]
+        z = M("Divide", M("Add", M("Subtract", M("Multiply", ia, ib), ia), M("Add", M("Multiply", ib, ib), ia)),
+              M("Subtract", M("Multiply", M("Subtract", ia, ib), ia), M("Multiply", M("Add", ib, ia), ib)))
+        got[join] = z.planes()
+        n = kc.stats()["kernel_launches"] - l0
+        assert (n == 1) if join else (n == 4), (join, n)
+    kc.set_option("join", 1)
+    assert_planes(got[1], [want], what="tree of joins")
+    assert_planes(got[0], got[1], what="join off == join on")
+
+
 @pytest.mark.parametrize("mode", [2, 1, 0])
 def test_config4_tree_with_and_without_its_kernels(kc, orc, mode):
     """BASELINE config #4's shape: 8 branches + a Mix(Add) tree.  mode 2: every program compiled at first sight -- 5 launches

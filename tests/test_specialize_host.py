@@ -43,9 +43,29 @@ def test_a_program_that_joins_two_chains():
     words = [word(ADD, 1), word(MUL, -1), word(SAVE_LOAD, 2), word(SUB_L, 3), word(SUBR_INV, SAVED), word(SAVE_LOAD, -1), word(MUL, SAVED)]
     src = kc.specialize_compile_check(words, n_in=4, start_src=0, flat=True)
     body = src[src.index('extern "C"'):]
-    assert "acc = (saved = acc, in2);" in body and "acc = acc - in3;" in body
-    assert "pp[2].a.c - (saved - acc)" in body  # saved (first chain) - acc (second chain), then c - that
-    assert "acc = (saved = acc, f4{ pp[2].b.c" in body and "acc = acc * saved;" in body
+    assert "acc = (saved0 = acc, in2);" in body and "acc = acc - in3;" in body
+    assert "pp[2].a.c - (saved0 - acc)" in body  # saved (first chain) - acc (second chain), then c - that
+    assert "acc = (saved0 = acc, f4{ pp[2].b.c" in body and "acc = acc * saved0;" in body
+
+
+def test_a_joined_chain_with_a_join_of_its_own():
+    """in0 op (in1 op (in2 op in3)) with every inner expression a chain of its own: the innermost join happens while two values
+    are aside (word bits 16-17 name the saved value)."""
+    lvl = lambda w, n: w | (n << 16)  # noqa: E731
+    words = [word(ADD, -1),                         # chain 0: in0 + c
+             word(SAVE_LOAD, 1), word(MUL, -1),     # saved0 = acc; chain 1: in1 * c
+             lvl(word(SAVE_LOAD, 2), 1),            # saved1 = acc; chain 2: in2 ...
+             word(SUB_L, 3),                        #   ... - in3
+             lvl(word(SUB_R, SAVED), 1),            # chain 1 - chain 2
+             word(DIV_R, SAVED)]                    # chain 0 / that
+    src = kc.specialize_compile_check(words, n_in=4, start_src=0, flat=True)
+    body = src[src.index('extern "C"'):]
+    assert "acc = (saved0 = acc, in1);" in body and "acc = (saved1 = acc, in2);" in body
+    assert "acc = saved1 - acc;" in body and "acc = saved0 / acc;" in body
+    with pytest.raises(kc.TexProError):
+        kc.specialize_compile_check([lvl(word(SAVE_LOAD, 1), 3)], n_in=2)  # only three values can be aside
+    with pytest.raises(kc.TexProError):
+        kc.specialize_compile_check([lvl(word(ADD, 1), 1)], n_in=2)        # a level on a step that names no saved value
 
 
 def test_constant_start_and_zero_inputs():
