@@ -80,6 +80,7 @@ try {
     if (const char *cp = std::getenv("KC_CACHE_POLICY")) c.cache_policy = std::atoi(cp) != 0;
     if (const char *c1 = std::getenv("KC_CHAIN1")) c.chain1 = std::atoi(c1) != 0;
     if (const char *j = std::getenv("KC_JOIN")) c.join = std::atoi(j) != 0;
+    if (const char *wd = std::getenv("KC_WIDE")) c.wide = std::atoi(wd) != 0;
     if (const char *d2 = std::getenv("KC_DOWN2")) c.down2 = std::max(0, std::min(2, std::atoi(d2)));
     if (const char *rt = std::getenv("KC_RESIZE_TILE_H")) c.resize_tile_h = std::atoi(rt);
     if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
@@ -235,6 +236,7 @@ try {
     if (std::strcmp(name, "chain1") == 0) ctx().chain1 = value != 0;
     else if (std::strcmp(name, "replay") == 0) ctx().replay = value != 0;
     else if (std::strcmp(name, "join") == 0) ctx().join = value != 0;
+    else if (std::strcmp(name, "wide") == 0) ctx().wide = value != 0;
     else if (std::strcmp(name, "down2") == 0 && value >= 0 && value <= 2) ctx().down2 = value;
     else {
         set_error(std::string("unknown option ") + name);
@@ -250,6 +252,7 @@ try {
     if (std::strcmp(name, "chain1") == 0) *value = ctx().chain1 ? 1 : 0;
     else if (std::strcmp(name, "replay") == 0) *value = ctx().replay ? 1 : 0;
     else if (std::strcmp(name, "join") == 0) *value = ctx().join ? 1 : 0;
+    else if (std::strcmp(name, "wide") == 0) *value = ctx().wide ? 1 : 0;
     else if (std::strcmp(name, "down2") == 0) *value = ctx().down2;
     else {
         set_error(std::string("unknown option ") + name);
@@ -358,7 +361,7 @@ KC_CATCH
 int kc_specialize_compile_check_upsample(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, uint32_t taps, int wide,
                                          char *source, size_t cap)
 try {
-    KC_ARG(words && n_ops >= 1 && n_ops <= (uint32_t)KC_CHAIN_MAX_OPS && n_in >= 1 && n_in <= (uint32_t)KC_CHAIN_MAX_IN);
+    KC_ARG(words && n_ops >= 1 && n_ops <= (uint32_t)KC_CHAIN_MAX_OPS && n_in >= 1 && n_in <= (uint32_t)KC_CHAIN_INTERP_IN);
     KC_ARG(start_src >= -1 && start_src < (int)n_in && (taps == 1 || taps == 3));
     ChainProgram P;
     std::memset(&P, 0, sizeof P);

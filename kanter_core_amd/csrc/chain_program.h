@@ -6,7 +6,9 @@
 // Fused pointwise chain: acc = start; for each step acc = op(acc, x) or op(x, acc).
 // One program drives up to KC_CHAIN_MAX_BATCH planes (the R, G, B planes of an RGBA Mix share
 // ops but not operands), blockIdx.y selects the plane.
-enum { KC_CHAIN_MAX_OPS = 64, KC_CHAIN_MAX_IN = 4, KC_CHAIN_MAX_BATCH = 4 };
+// KC_CHAIN_MAX_IN input planes per channel fit a program; the interpreter, the one-step kernels and the fused resize kernels
+// handle KC_CHAIN_INTERP_IN of them: a program with more runs on its own compiled kernel only (runtime.cpp chain_launch).
+enum { KC_CHAIN_MAX_OPS = 64, KC_CHAIN_MAX_IN = 8, KC_CHAIN_INTERP_IN = 4, KC_CHAIN_MAX_BATCH = 4 };
 
 // Step codes: which side the running value sits on matters for -, / and pow.
 enum ChainCode : unsigned char {
@@ -53,7 +55,7 @@ struct ChainProgram {
     unsigned int row_units;  // vector units (float4 or float) per row; rows * row_units = work items
     unsigned int rows;
     int start_src;  // input index, or -1: start from start_c
-    // Cache policy of this launch, chosen by the host (runtime.cpp, cache_policy_mask): bit k = input plane k is read with
+    // Cache policy of this launch, chosen by the host (runtime.cpp, cache_policy_mask): bit k (k < 8) = input plane k is read with
     // the nontemporal hint (streamed once, not worth a place in the 256 MB Infinity Cache), bit 8 = the result is stored
     // with it.  Honoured by the kernels compiled at run time and by the up-sampling kernels; a hint, never semantics.
     unsigned int nt_mask;

@@ -144,7 +144,9 @@ struct ChainLink : Pooled<ChainLink> {
     kc_plane *prev = nullptr;   // retained; the LAZY plane continued, or nullptr
     kc_plane *start = nullptr;  // retained; the chain's first value when prev == nullptr
     ChainStep step{};           // operand retained
-    uint32_t length = 1;        // steps up to and including this one (an upper bound once a prev was forced)
+    uint32_t length = 1;        // RECORDS up to and including this step (an upper bound once a prev was forced): a step that
+                                // chain_fill folds into its predecessor's record (CH_*_INV) does not count
+    bool fused = false;         // this step is such a folded one
     uint8_t saved = 0;          // saved values the chain needs at once: 0 = no joined chain, 1 = joins of plain chains, ...
     int n_in = 0;               // distinct MEM / RESIZE planes the whole chain reads (same bound)
     // Their identities BY VALUE (device pointer + pitch of a resident plane, address of a deferred resize):
@@ -198,7 +200,7 @@ struct TapsEntry {
 struct ReplayLaunch {
     ChainProgram prog;  // as launched: input and output pointers of the recorded run
     int batch = 0, mode = 0;
-    uint32_t in_refs[KC_CHAIN_MAX_IN] = { 0, 0, 0, 0 };
+    uint32_t in_refs[KC_CHAIN_MAX_IN] = {};
     uint32_t w = 0, h = 0;
     kc_plane *planes[KC_CHAIN_MAX_BATCH] = { nullptr, nullptr, nullptr, nullptr };  // the lazy planes the launch made resident
     // filled when the recording is closed: input (b, k) is output channel in_ch of recorded launch in_from (-1: a plane that
@@ -222,6 +224,7 @@ struct Context {
     bool fusion = true;
     bool replay = true;  // an evaluation that repeats the recorded one is replayed without the walk (kc_set_option("replay", 0); env KC_REPLAY)
     int down2 = 1;       // resize_down2_kernel: 0 off, 1 except where resize_poly_kernel runs at ratio 4 or 8, 2 there too (kc_set_option("down2"); env KC_DOWN2)
+    bool wide = true;    // chains of up to KC_CHAIN_MAX_IN input planes (compiled kernels only); 0: KC_CHAIN_INTERP_IN as before (kc_set_option("wide"); env KC_WIDE)
     bool join = true;    // a Mix of two unevaluated chains keeps both in one program (kc_set_option("join", 0); env KC_JOIN)
     bool chain1 = true;  // one-step programs run the ahead-of-time kernels of chain1.hip (kc_set_option("chain1", 0): interpreter / specialiser, A/B and tests)
     int cache_policy = 1;  // 1: launches whose streams exceed the Infinity Cache mark them nontemporal (cache_policy_mask); 0: plain loads / stores (KC_CACHE_POLICY, kc_set_cache_policy)

@@ -288,6 +288,15 @@ ChainLink::~ChainLink()
     }
 }
 
+// Input planes a chain may gather while it is being built: KC_CHAIN_MAX_IN when programs get kernels of their own (more than
+// KC_CHAIN_INTERP_IN run on nothing else; chain_launch splits the chain while such a kernel is not there), else what the
+// interpreter handles.
+static int chain_in_limit()
+{
+    const Context &c = ctx();
+    return (c.wide && c.fusion && specialize_get_mode() != 0) ? KC_CHAIN_MAX_IN : KC_CHAIN_INTERP_IN;
+}
+
 // Identity of a chain input, as input_index() sees it, as a value (see ChainLink::InKey).
 static void link_add_input(ChainLink &L, const kc_plane *q)
 {
@@ -315,6 +324,22 @@ static int chain_distinct_inputs(const Chain &ch)
     for (auto &s : ch.steps)
         if (counts(s.operand)) input_index(ins, s.operand);
     return (int)ins.size();
+}
+
+// Records chain_fill will write for a flat chain: a {+, -, *} step on a plane (or a saved value) followed by "constant - acc"
+// is one record (CH_*_INV).
+static size_t chain_record_count(const Chain &ch)
+{
+    size_t r = 0;
+    for (size_t i = 0; i < ch.steps.size(); ++i, ++r) {
+        const ChainStep &st = ch.steps[i];
+        uint8_t code = st.code == CH_ADD_R ? (uint8_t)CH_ADD : st.code == CH_MUL_R ? (uint8_t)CH_MUL : st.code;
+        const bool plane = st.operand == saved_value_marker() || st.operand->kind != kc_plane::CONST;
+        if (plane && code <= CH_MUL && i + 1 < ch.steps.size() && ch.steps[i + 1].code == CH_SUB_R &&
+            ch.steps[i + 1].operand->kind == kc_plane::CONST && ch.steps[i + 1].operand != saved_value_marker())
+            ++i;
+    }
+    return r;
 }
 
 // Builds p->chain (start + steps in order) from the links; planes forced meanwhile end the walk.  A step whose operand is a
@@ -388,7 +413,7 @@ Operand plane_operand(const kc_plane *p)
 // ---- building the kernel program for one lazy plane -------------------------------------
 struct BuiltChain {
     ChainProgram prog;
-    uint32_t in_refs[KC_CHAIN_MAX_IN] = { 0, 0, 0, 0 };  // reference counts of channel 0's resident inputs when the program was built
+    uint32_t in_refs[KC_CHAIN_MAX_IN] = {};  // reference counts of channel 0's resident inputs when the program was built
     int mode = 0;  // 0 = {+,-,*}, 1 = + divide, 2 = + pow
     kc_plane *sampled[KC_CHAIN_MAX_BATCH] = { nullptr, nullptr, nullptr, nullptr };  // RESIZE operand per channel
     bool joins = false;  // the program holds CH_SAVE_LOAD: only its own compiled kernel can run it
@@ -617,6 +642,7 @@ hipError_t chain_dispatch(ChainProgram &P, int batch, int mode, uint32_t w, uint
         // ... otherwise the interpreter -- which does not know the codes of a program that joins two chains (chain_launch
         // never sends it one; a replay of such a launch after kc_set_specialize(0) can)
         if (e == hipSuccess && !launched) {
+            if (P.n_in > (uint32_t)KC_CHAIN_INTERP_IN) return hipErrorNotReady;  // as below: compiled kernels only
             for (uint32_t i = 0; i < P.n_ops; ++i)
                 if ((((i & 1u) ? P.step[0][i / 2].b.word : P.step[0][i / 2].a.word) & 0xffu) == CH_SAVE_LOAD) return hipErrorNotReady;
             e = launch_chain(P, batch, mode, c.max_blocks, c.chain_unroll, c.stream);
@@ -626,7 +652,7 @@ hipError_t chain_dispatch(ChainProgram &P, int batch, int mode, uint32_t w, uint
     return hipSuccess;
 }
 
-static int chain_flatten_to_fit(kc_plane *p);
+static int chain_flatten_to_fit(kc_plane *p, int limit);
 
 static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 {
@@ -663,19 +689,20 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
     }
     if (!launched) {
         hipError_t e = chain_dispatch(P, batch, bc.mode, p0->w, p0->h, outs[0]->pitch);
-        if (e == hipErrorNotReady && bc.joins) {
-            // The program joins two chains and its kernel has not been compiled (yet): the joined chains run on their own,
-            // as they did before joins existed, and the caller rebuilds the program around their results.
+        if (e == hipErrorNotReady && (bc.joins || P.n_in > (uint32_t)KC_CHAIN_INTERP_IN)) {
+            // The program joins chains or reads more planes than the interpreter handles, and its own kernel has not been
+            // compiled (yet): the joined chains run on their own and the chain is cut to the interpreter's input count, as
+            // both were before such programs existed; the caller rebuilds the program around the results.
             for (auto *o : outs) plane_release(o);
             std::vector<kc_plane *> subs;
             for (int b = 0; b < batch; ++b)
                 for (auto *j : planes[b]->chain->joined) subs.push_back(j);
-            KC_TRY(planes_force(subs.data(), (int)subs.size()));
+            if (!subs.empty()) KC_TRY(planes_force(subs.data(), (int)subs.size()));
             for (int b = 0; b < batch; ++b) {
                 if (planes[b]->kind != kc_plane::LAZY) continue;  // ran as one of the joined chains' inputs (planes_force skips it)
                 delete planes[b]->chain;
                 planes[b]->chain = nullptr;
-                KC_TRY(chain_flatten_to_fit(planes[b]));
+                KC_TRY(chain_flatten_to_fit(planes[b], KC_CHAIN_INTERP_IN));
             }
             c.counters["join_fallbacks"]++;
             if (c.capture) c.capture->ok = false;  // not what this evaluation will do once the kernel is there: do not record it
@@ -686,6 +713,7 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
             return hip_fail(e, "launch_chain");
         }
         if (bc.joins) c.counters["join_launches"]++;
+        if (P.n_in > (uint32_t)KC_CHAIN_INTERP_IN) c.counters["wide_launches"]++;
     }
     c.launches++;
     {
@@ -737,10 +765,11 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 // Flattens p's chain.  The input count was bounded when the chain was built, but a constant operand can have been
 // materialised since (kc_plane_materialize, a resize of it ...) and now occupies an input slot, and joined chains that had to
 // run on their own (chain_launch) each became one.  Then the prefix is run on its own and the chain restarts from its result.
-static int chain_flatten_to_fit(kc_plane *p)
+static int chain_flatten_to_fit(kc_plane *p, int limit)
 {
     chain_flatten(p);
-    while (chain_distinct_inputs(*p->chain) > KC_CHAIN_MAX_IN) {
+    // (ChainLink::length counts a fusable pair as one record; a constant that has been materialised since no longer fuses)
+    while (chain_distinct_inputs(*p->chain) > limit || chain_record_count(*p->chain) > (size_t)KC_CHAIN_MAX_OPS) {
         if (!p->chain->joined.empty()) {
             // Joined chains bring their own inputs along.  The bound plane_mix checked (join_ok) held for the chains as they
             // were then; a prefix that has been run since counts as ONE new input beside them.  Run the joined chains: each
@@ -758,7 +787,7 @@ static int chain_flatten_to_fit(kc_plane *p)
         }
         kc_plane *prev = p->link->prev;
         if (!prev || prev->kind != kc_plane::LAZY) {
-            set_error("chain with more than KC_CHAIN_MAX_IN inputs cannot be split");
+            set_error("chain with more inputs than a program holds cannot be split");
             return KC_ERR_UNSUPPORTED;
         }
         KC_TRY(plane_force(prev));
@@ -789,8 +818,19 @@ int planes_force(kc_plane *const *planes, int n)
         // forcing a prefix or an operand below can run another plane of this very list (an image may hold a chain and
         // its own prefix): it is resident then and has nothing left to flatten
         if (p->kind != kc_plane::LAZY) continue;
-        KC_TRY(chain_flatten_to_fit(p));
+        // (a resampled operand goes through the fused resize + chain kernels: the interpreter's input count)
+        KC_TRY(chain_flatten_to_fit(p, chain_in_limit()));
         if (p->kind != kc_plane::LAZY) continue;
+        {
+            bool resampled = p->chain->start->kind == kc_plane::RESIZE;
+            for (auto &st : p->chain->steps) resampled |= st.operand->kind == kc_plane::RESIZE;
+            if (resampled && chain_distinct_inputs(*p->chain) > KC_CHAIN_INTERP_IN) {
+                delete p->chain;
+                p->chain = nullptr;
+                KC_TRY(chain_flatten_to_fit(p, KC_CHAIN_INTERP_IN));
+                if (p->kind != kc_plane::LAZY) continue;
+            }
+        }
         KC_TRY(chain_prepare(p));
     }
     todo.erase(std::remove_if(todo.begin(), todo.end(), [](kc_plane *q) { return q->kind != kc_plane::LAZY; }), todo.end());
@@ -802,7 +842,7 @@ int planes_force(kc_plane *const *planes, int n)
             continue;
         }
         if (!todo[i]->chain) {
-            KC_TRY(chain_flatten_to_fit(todo[i]));
+            KC_TRY(chain_flatten_to_fit(todo[i], KC_CHAIN_INTERP_IN));
             if (todo[i]->kind != kc_plane::LAZY) continue;
         }
         BuiltChain bc;
@@ -882,12 +922,16 @@ static uint8_t code_for(int mix, bool acc_is_left)
 static bool chain_full_with(const kc_plane *acc, const kc_plane *opnd)
 {
     if (acc->link->length >= (uint32_t)KC_CHAIN_MAX_OPS) return true;
-    if (acc->link->n_in < KC_CHAIN_MAX_IN) return false;  // one more operand adds at most one input
+    int limit = chain_in_limit();
+    if (opnd->kind == kc_plane::RESIZE) limit = KC_CHAIN_INTERP_IN;  // the fused resize + chain kernels
+    for (int i = 0; i < acc->link->n_in && i <= KC_CHAIN_MAX_IN; ++i)
+        if (acc->link->ins[i].q == ~(size_t)0) limit = KC_CHAIN_INTERP_IN;
+    if (acc->link->n_in < limit) return false;  // one more operand adds at most one input
     ChainLink probe;
     probe.n_in = acc->link->n_in;
     for (int i = 0; i < probe.n_in && i <= KC_CHAIN_MAX_IN; ++i) probe.ins[i] = acc->link->ins[i];
     link_add_input(probe, opnd);
-    return acc->link->length >= (uint32_t)KC_CHAIN_MAX_OPS || probe.n_in > KC_CHAIN_MAX_IN;
+    return probe.n_in > limit;
 }
 
 // Which of two lazy operands plane_mix runs first: the shorter chain (the right one on a tie).
@@ -909,7 +953,8 @@ static bool join_ok(const kc_plane *acc, const kc_plane *sub)
     Context &c = ctx();
     if (!c.join || !c.fusion || acc == sub || specialize_get_mode() == 0) return false;
     const ChainLink &A = *acc->link, &B = *sub->link;
-    if (std::max<int>(A.saved, B.saved + 1) > KC_CHAIN_MAX_SAVED || A.n_in > KC_CHAIN_MAX_IN - 1 || B.n_in > KC_CHAIN_MAX_IN) return false;
+    const int limit = chain_in_limit();
+    if (std::max<int>(A.saved, B.saved + 1) > KC_CHAIN_MAX_SAVED || A.n_in > limit - 1 || B.n_in > limit) return false;
     if (A.length + B.length + 2u > (uint32_t)KC_CHAIN_MAX_OPS) return false;
     ChainLink probe;
     probe.n_in = A.n_in;
@@ -922,7 +967,7 @@ static bool join_ok(const kc_plane *acc, const kc_plane *sub)
         bool seen = false;
         for (int k = 0; k < probe.n_in && k <= KC_CHAIN_MAX_IN; ++k) seen |= probe.ins[k] == B.ins[i];
         if (!seen) {
-            if (probe.n_in >= KC_CHAIN_MAX_IN) return false;
+            if (probe.n_in >= limit) return false;
             probe.ins[probe.n_in++] = B.ins[i];
         }
     }
@@ -1022,7 +1067,14 @@ int plane_mix(int mix, kc_plane *l, kc_plane *r, kc_plane **out)
         plane_retain(acc);
         L->step = { code_for(mix, acc_is_left), opnd };
         plane_retain(opnd);
-        L->length = acc->link->length + (join ? opnd->link->length + 2u : 1u);
+        // records, as chain_fill will write them: "constant - acc" right after a {+, -, *} step on a plane is part of that
+        // step's record (CH_*_INV)
+        const ChainStep &last = acc->link->step;
+        const uint8_t lc = last.code == CH_ADD_R ? (uint8_t)CH_ADD : last.code == CH_MUL_R ? (uint8_t)CH_MUL : last.code;
+        const bool fuses = !join && L->step.code == CH_SUB_R && opnd->kind == kc_plane::CONST && lc <= CH_MUL &&
+                           last.operand->kind != kc_plane::CONST && !acc->link->fused;
+        L->fused = fuses;
+        L->length = acc->link->length + (join ? opnd->link->length + 2u : fuses ? 0u : 1u);
         L->saved = join ? (uint8_t)std::max<int>(acc->link->saved, opnd->link->saved + 1) : acc->link->saved;
     } else {
         L->prev = nullptr;

@@ -27,7 +27,20 @@ def gray(kc, p):
     return kc.SlotImage.from_planes([p])
 
 
-def test_long_chain_is_cut_at_64_steps_and_4_planes(kc, orc):
+@pytest.mark.parametrize("wide", [0, 1])
+def test_long_chain_is_cut_at_64_steps_and_4_planes(kc, orc, wide):
+    """wide = 0: chains hold 4 input planes (what the interpreter handles); wide = 1 (the default): 8, on kernels compiled for the
+    program (compiled at first sight here) -- 7 planes fit, only the 64-record limit cuts."""
+    kc.set_option("wide", wide)
+    kc.set_specialize(2)
+    try:
+        _long_chain(kc, orc, wide)
+    finally:
+        kc.set_option("wide", 1)
+        kc.set_specialize(1)
+
+
+def _long_chain(kc, orc, wide):
     h, w = 24, 40
     planes = [splitmix_plane(SEED_A + i, 0, h, w) * np.float32(0.5) + np.float32(0.25) for i in range(7)]
     imgs = [gray(kc, p) for p in planes]
@@ -46,7 +59,10 @@ def test_long_chain_is_cut_at_64_steps_and_4_planes(kc, orc):
     got = x.planes()
     launches = kc.stats()["kernel_launches"] - l0
     assert_planes(got, [want], what="150-step chain")
-    assert 3 <= launches <= 150 // 3, launches   # cut every ~3-4 steps here (each restart spends one of the 4 input slots)
+    if wide:
+        assert launches == 3, launches               # 150 steps, 64 records per program
+    else:
+        assert 3 <= launches <= 150 // 3, launches   # cut every ~3-4 steps here (each restart spends one of the 4 input slots)
 
 
 def test_diamond_both_operands_lazy(kc, orc):
