@@ -1056,8 +1056,17 @@ int kc_live_graph::await_clean(uint32_t id)
     bool replayed = false;
     KC_TRY(replay_try(*this, id, &replayed));
     if (replayed) return KC_OK;
+    // A graph's FIRST evaluation builds its chains the way every kernel can run them (4 input planes, no joined chains): a
+    // process that evaluates a graph once must not pay for programs whose own kernels it will never see compiled.  From the
+    // second evaluation on the chains are built for those kernels (csrc/runtime.cpp chain_in_limit / join_ok); "compile at
+    // first sight" (kc_set_specialize(2)) has them from the start.
+    Context &c = ctx();
+    const bool plain_before = c.plain_chains;
+    c.plain_chains = plain_before || (walks == 0 && specialize_get_mode() == 1);
     ReplayRecorder *rec = replay_begin(*this, id);
     const int s = await_clean_walk(id);
+    c.plain_chains = plain_before;
+    ++walks;
     replay_end(*this, id, rec, s);
     return s;
 }

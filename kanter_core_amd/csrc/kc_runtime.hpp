@@ -224,6 +224,7 @@ struct Context {
     bool fusion = true;
     bool replay = true;  // an evaluation that repeats the recorded one is replayed without the walk (kc_set_option("replay", 0); env KC_REPLAY)
     int down2 = 1;       // resize_down2_kernel: 0 off, 1 except where resize_poly_kernel runs at ratio 4 or 8, 2 there too (kc_set_option("down2"); env KC_DOWN2)
+    bool plain_chains = false;  // set during a graph's first evaluation: chains as the interpreter runs them (4 planes, no joins)
     bool wide = true;    // chains of up to KC_CHAIN_MAX_IN input planes (compiled kernels only); 0: KC_CHAIN_INTERP_IN as before (kc_set_option("wide"); env KC_WIDE)
     bool join = true;    // a Mix of two unevaluated chains keeps both in one program (kc_set_option("join", 0); env KC_JOIN)
     bool chain1 = true;  // one-step programs run the ahead-of-time kernels of chain1.hip (kc_set_option("chain1", 0): interpreter / specialiser, A/B and tests)
@@ -566,6 +567,7 @@ struct kc_live_graph {
     std::unordered_set<uint32_t> changed;  // reported in ascending id order (kc_live_graph_changed_consume)
     bool auto_update = false;
     bool use_cache = false;
+    uint64_t walks = 0;  // evaluations that were walked (not replayed): the first one builds plain chains, see await_clean
     std::string base_dir;
     int depth = 0;  // nesting depth of Graph nodes (recursion guard)
     struct ReplayEntry;

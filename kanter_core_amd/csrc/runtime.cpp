@@ -294,7 +294,7 @@ ChainLink::~ChainLink()
 static int chain_in_limit()
 {
     const Context &c = ctx();
-    return (c.wide && c.fusion && specialize_get_mode() != 0) ? KC_CHAIN_MAX_IN : KC_CHAIN_INTERP_IN;
+    return (c.wide && c.fusion && !c.plain_chains && specialize_get_mode() != 0) ? KC_CHAIN_MAX_IN : KC_CHAIN_INTERP_IN;
 }
 
 // Identity of a chain input, as input_index() sees it, as a value (see ChainLink::InKey).
@@ -951,7 +951,7 @@ static kc_plane *lazy_pair_victim(kc_plane *l, kc_plane *r)
 static bool join_ok(const kc_plane *acc, const kc_plane *sub)
 {
     Context &c = ctx();
-    if (!c.join || !c.fusion || acc == sub || specialize_get_mode() == 0) return false;
+    if (!c.join || !c.fusion || c.plain_chains || acc == sub || specialize_get_mode() == 0) return false;
     const ChainLink &A = *acc->link, &B = *sub->link;
     const int limit = chain_in_limit();
     if (std::max<int>(A.saved, B.saved + 1) > KC_CHAIN_MAX_SAVED || A.n_in > limit - 1 || B.n_in > limit) return false;
