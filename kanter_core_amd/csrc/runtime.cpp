@@ -790,6 +790,41 @@ static int chain_flatten_to_fit(kc_plane *p, int limit)
             set_error("chain with more inputs than a program holds cannot be split");
             return KC_ERR_UNSUPPORTED;
         }
+        // The longest prefix that fits -- not simply the chain minus its last step, which would run every further step as a
+        // launch of its own once the first cut has been made.  Walk the links forward from the chain's start, counting input
+        // planes as chain_fill will see them.
+        {
+            std::vector<kc_plane *> path;  // the lazy planes from the first link to p's predecessor
+            for (kc_plane *q = prev; q && q->kind == kc_plane::LAZY; q = q->link->prev) path.push_back(q);
+            std::reverse(path.begin(), path.end());
+            std::vector<ChainLink::InKey> keys;
+            auto add = [&](const kc_plane *q) {
+                ChainLink::InKey k;
+                if (q->kind == kc_plane::MEM) k = { q->dptr, q->pitch };
+                else if (q->kind == kc_plane::RESIZE) k = { q, ~(size_t)0 };
+                else return;
+                if (std::find(keys.begin(), keys.end(), k) == keys.end()) keys.push_back(k);
+            };
+            const ChainLink &first = *path[0]->link;
+            add(first.prev ? first.prev : first.start);
+            kc_plane *cut = nullptr;
+            size_t steps = 0;
+            for (kc_plane *q : path) {
+                const kc_plane *o = q->link->step.operand;
+                if (o->kind == kc_plane::LAZY) {  // a joined chain brings its inputs along
+                    for (int i = 0; i < o->link->n_in && i <= KC_CHAIN_MAX_IN; ++i)
+                        if (std::find(keys.begin(), keys.end(), o->link->ins[i]) == keys.end()) keys.push_back(o->link->ins[i]);
+                    steps += o->link->length + 2u;
+                    if (o->link->n_in > KC_CHAIN_MAX_IN) break;
+                } else {
+                    add(o);
+                    ++steps;
+                }
+                if ((int)keys.size() > limit || steps > (size_t)KC_CHAIN_MAX_OPS) break;
+                cut = q;
+            }
+            if (cut) prev = cut;
+        }
         KC_TRY(plane_force(prev));
         delete p->chain;
         p->chain = nullptr;
