@@ -694,9 +694,10 @@ static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
             // compiled (yet): the joined chains run on their own and the chain is cut to the interpreter's input count, as
             // both were before such programs existed; the caller rebuilds the program around the results.
             for (auto *o : outs) plane_release(o);
-            std::vector<kc_plane *> subs;
-            for (int b = 0; b < batch; ++b)
-                for (auto *j : planes[b]->chain->joined) subs.push_back(j);
+            std::vector<kc_plane *> subs;  // channel by channel for each joined chain: planes_force batches neighbours
+            for (size_t j = 0; j < planes[0]->chain->joined.size(); ++j)
+                for (int b = 0; b < batch; ++b)
+                    if (j < planes[b]->chain->joined.size()) subs.push_back(planes[b]->chain->joined[j]);
             if (!subs.empty()) KC_TRY(planes_force(subs.data(), (int)subs.size()));
             for (int b = 0; b < batch; ++b) {
                 if (planes[b]->kind != kc_plane::LAZY) continue;  // ran as one of the joined chains' inputs (planes_force skips it)
