@@ -954,28 +954,33 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
         resize_down_tile<4>(S, src, spitch, dst, dpitch, B.ty0[t], B.th[t], V, wave, lane);
         return;
     }
-    __syncthreads();  // the strip's horizontal taps
+    // The band's first rows are requested BEFORE the barrier behind the strip's horizontal taps: the taps' staging (global reads)
+    // and these loads are in flight together.  A wave without a band still takes the barrier.
     const uint32_t bi = by * 4u + wave;
-    if (bi >= B.n_bands) return;
-    const uint32_t yf = B.ya + B.rows * bi;
+    const bool has_band = bi < B.n_bands;
+    const uint32_t yf = B.ya + B.rows * (has_band ? bi : 0u);
     const uint32_t ROWS = min(B.rows, B.yb - yf);
+    const uint32_t sp4 = spitch / 4u;
+    const bool q_ok = lane < S.nq;
+    const uint32_t q = min(lane, S.nq - 1u);
+    const f4 *col = reinterpret_cast<const f4 *>(src + S.c0) + q + (size_t)V.left[yf] * sp4;
+    f4 pn[RT];
+    if (has_band) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)u * sp4];
+    }
+    __syncthreads();  // the strip's horizontal taps
+    if (!has_band) return;
     float W[A][RT];
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
         for (int u = 0; u < RT; ++u) W[a][u] = V.w[(size_t)B.ya * V.stride + a * RT + u];  // scalar registers (vector ones measured slower)
-    const uint32_t sp4 = spitch / 4u;
-    const bool q_ok = lane < S.nq;
-    const uint32_t q = min(lane, S.nq - 1u);
-    const f4 *col = reinterpret_cast<const f4 *>(src + S.c0) + q + (size_t)V.left[yf] * sp4;
     float *ring = S.tmp + wave * 4u * S.row_floats;
     float *ringq = ring + 4u * q + (q >> 3);  // swizzled: a quad never straddles a multiple of 32
     f4 acc[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) acc[a] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
-    f4 pn[RT];
-#pragma unroll
-    for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)u * sp4];
     const uint32_t TRIPS = ROWS + A - 1;
     for (uint32_t c = 0; c < TRIPS; ++c) {
         f4 p[RT];
