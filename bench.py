@@ -348,11 +348,21 @@ def main():
     def warm(stepfn, warmup):
         # The first sightings of a chain program run through the interpreter while the program-specialised kernel
         # compiles on a worker thread (csrc/specialize.cpp); the rest of the warm-up starts once it has landed.
-        early = min(warmup, 2)
+        # A graph's first evaluation builds plain chains and the programs that join chains / read more than four planes are
+        # first seen at the second one (csrc/graph.cpp await_clean), so compiles are queued in up to three waves: pairs of
+        # steps, each followed by a wait, until a pair queues nothing new.
+        early = 0
         c0 = kc.specialize_stats()["kernels_compiled"]
-        for _ in range(early):
+        for _ in range(4):
+            if early + 2 > warmup:
+                break
+            c1 = kc.specialize_stats()["kernels_compiled"]
             stepfn()
-        kc.specialize_wait()
+            stepfn()
+            early += 2
+            kc.specialize_wait()
+            if early > 2 and kc.specialize_stats()["kernels_compiled"] == c1:
+                break
         # The GPU sat idle while hiprtc ran (~2 s for the first program of a process) and its clocks went down with it:
         # when a compile did land, a few more untimed steps bring them back before the timed region (which stays EXACTLY
         # `steps` steps; the JSON reports the requested warm-up count and these extra ones separately).

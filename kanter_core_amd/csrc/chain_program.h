@@ -8,7 +8,10 @@
 // ops but not operands), blockIdx.y selects the plane.
 // KC_CHAIN_MAX_IN input planes per channel fit a program; the interpreter, the one-step kernels and the fused resize kernels
 // handle KC_CHAIN_INTERP_IN of them: a program with more runs on its own compiled kernel only (runtime.cpp chain_launch).
-enum { KC_CHAIN_MAX_OPS = 64, KC_CHAIN_MAX_IN = 8, KC_CHAIN_INTERP_IN = 4, KC_CHAIN_MAX_BATCH = 4 };
+enum { KC_CHAIN_MAX_OPS = 80, KC_CHAIN_MAX_IN = 16, KC_CHAIN_INTERP_IN = 4, KC_CHAIN_MAX_BATCH = 4 };
+// (sizes: the argument block -- 16 x 4 pointers and pitches, 41 x 4 record pairs -- is 3.6 KB of the 4 KB a launch may pass)
+// Cache-policy bit of input plane k in ChainProgram::nt_mask: bits 0-7, then 16-23 (bit 8 is the result's).
+#define KC_CHAIN_NT_BIT(k) ((k) < 8 ? 1u << (k) : 1u << ((k) + 8))
 
 // Step codes: which side the running value sits on matters for -, / and pow.
 enum ChainCode : unsigned char {
@@ -37,7 +40,7 @@ enum ChainCode : unsigned char {
 };
 // Operand source (word bits 8-15) KC_CHAIN_SRC_SAVED: the value CH_SAVE_LOAD put aside.  A joined chain can hold joins of its
 // own: KC_CHAIN_MAX_SAVED values can be aside at once, word bits 16-17 say which one a CH_SAVE_LOAD writes / a step reads.
-enum { KC_CHAIN_SRC_SAVED = 15, KC_CHAIN_MAX_SAVED = 3 };
+enum { KC_CHAIN_SRC_SAVED = 255, KC_CHAIN_MAX_SAVED = 3 };  // (255: clear of k + 1 for every input plane k)
 
 // word: bits 0-7 ChainCode, bits 8-15 operand source (0 = the constant c, k + 1 = input plane k, KC_CHAIN_SRC_SAVED), bits 16-17
 // the saved value meant (CH_SAVE_LOAD, KC_CHAIN_SRC_SAVED).
@@ -55,7 +58,7 @@ struct ChainProgram {
     unsigned int row_units;  // vector units (float4 or float) per row; rows * row_units = work items
     unsigned int rows;
     int start_src;  // input index, or -1: start from start_c
-    // Cache policy of this launch, chosen by the host (runtime.cpp, cache_policy_mask): bit k (k < 8) = input plane k is read with
+    // Cache policy of this launch, chosen by the host (runtime.cpp, cache_policy_mask): KC_CHAIN_NT_BIT(k) = input plane k is read with
     // the nontemporal hint (streamed once, not worth a place in the 256 MB Infinity Cache), bit 8 = the result is stored
     // with it.  Honoured by the kernels compiled at run time and by the up-sampling kernels; a hint, never semantics.
     unsigned int nt_mask;

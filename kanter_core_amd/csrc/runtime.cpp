@@ -560,18 +560,20 @@ uint32_t chain_cache_policy(const uint32_t *refs, uint32_t n, uint64_t stream_by
 {
     if (!ctx().cache_policy) return 0;
     static const long forced = std::getenv("KC_NT_FORCE") ? std::strtol(std::getenv("KC_NT_FORCE"), nullptr, 0) : -1;  // tuning: this mask for every launch
-    if (forced >= 0) return (uint32_t)forced & (((1u << n) - 1u) | 0x100u);
+    uint32_t all = 0;
+    for (uint32_t k = 0; k < n; ++k) all |= KC_CHAIN_NT_BIT(k);
+    if (forced >= 0) return (uint32_t)forced & (all | 0x100u);
     const uint64_t budget = 208ull << 20;
     if (n * stream_bytes + out_bytes <= budget) return 0;
-    uint32_t mask = (1u << n) - 1u;
+    uint32_t mask = all;
     uint64_t used = 0;
     for (;;) {
         int best = -1;
         for (uint32_t k = 0; k < n; ++k)
-            if ((mask >> k & 1u) && refs[k] >= 2 && (best < 0 || refs[k] > refs[best])) best = (int)k;
+            if ((mask & KC_CHAIN_NT_BIT(k)) && refs[k] >= 2 && (best < 0 || refs[k] > refs[best])) best = (int)k;
         if (best < 0 || used + stream_bytes > budget) break;
         used += stream_bytes;
-        mask &= ~(1u << best);
+        mask &= ~KC_CHAIN_NT_BIT(best);
     }
     if (used + out_bytes > budget) mask |= 0x100u;
     return mask;
@@ -653,6 +655,7 @@ hipError_t chain_dispatch(ChainProgram &P, int batch, int mode, uint32_t w, uint
 }
 
 static int chain_flatten_to_fit(kc_plane *p, int limit);
+static_assert(sizeof(ChainProgram) <= 4096, "a launch passes at most 4 KB of kernel arguments");
 
 static int chain_launch(BuiltChain &bc, kc_plane *const *planes, int batch)
 {

@@ -29,8 +29,8 @@ def gray(kc, p):
 
 @pytest.mark.parametrize("wide", [0, 1])
 def test_long_chain_is_cut_at_64_steps_and_4_planes(kc, orc, wide):
-    """wide = 0: chains hold 4 input planes (what the interpreter handles); wide = 1 (the default): 8, on kernels compiled for the
-    program (compiled at first sight here) -- 7 planes fit, only the 64-record limit cuts."""
+    """wide = 0: chains hold 4 input planes (what the interpreter handles); wide = 1 (the default): 16, on kernels compiled for the
+    program (compiled at first sight here) -- 7 planes fit, only the 80-record limit cuts."""
     kc.set_option("wide", wide)
     kc.set_specialize(2)
     try:
@@ -60,7 +60,7 @@ def _long_chain(kc, orc, wide):
     launches = kc.stats()["kernel_launches"] - l0
     assert_planes(got, [want], what="150-step chain")
     if wide:
-        assert launches == 3, launches               # 150 steps, 64 records per program
+        assert launches == 2, launches               # 150 steps, 80 records per program
     else:
         assert 3 <= launches <= 150 // 3, launches   # cut every ~3-4 steps here (each restart spends one of the 4 input slots)
 

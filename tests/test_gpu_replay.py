@@ -239,6 +239,7 @@ def test_an_evaluation_of_several_launches_is_replayed(kc, orc, n_branches, sub_
     # programs that join two chains (tests/test_gpu_join.py) are compiled at first sight here: while such a kernel is still
     # being compiled an evaluation falls back to separate launches and is deliberately not recorded
     kc.set_specialize(2)
+    kc.set_option("wide", 0)  # programs of 4 input planes: the graph stays a SEQUENCE of launches, which is what this test replays
     kc.set_option("replay", 1)
     tp1, lg1, plugs1, root1 = fanin_live(kc, sources, sub_nodes)
     kc.set_option("replay", 0)
@@ -285,3 +286,4 @@ def test_an_evaluation_of_several_launches_is_replayed(kc, orc, n_branches, sub_
         got = lg1.await_clean(root1).slot_data(root1, 0).image.planes()
         assert_planes(got, want, what="another source, evaluation %d" % rep)
     kc.set_specialize(1)
+    kc.set_option("wide", 1)

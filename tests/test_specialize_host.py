@@ -8,7 +8,7 @@ import kanter_core_amd as kc
 ADD, SUB_L, SUB_R, MUL, DIV_L, DIV_R, POW_L, POW_R = range(8)
 ADD_INV, SUBL_INV, SUBR_INV, MUL_INV = 10, 11, 12, 13
 SAVE_LOAD = 14  # saved = acc; acc = x: a second chain inside the program (csrc/chain_program.h)
-SAVED = 14      # operand source index of the saved value (word bits 8-15 = 15)
+SAVED = 254     # operand source index of the saved value (word bits 8-15 = 255)
 
 
 def word(code, src):
