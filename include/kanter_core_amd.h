@@ -147,7 +147,7 @@ KC_API int kc_get_cache_policy(void);
  *   "join" 1 (default): a Mix whose two inputs are both chains that have not run keeps both in one program -- one launch,
  *   no plane in between (csrc/runtime.cpp plane_mix; only kernels compiled at run time implement it, and while such a kernel
  *   is not there the second chain runs on its own as before); 0: always run it on the spot.  Bit-identical either way.
- *   "wide" 1 (default): a fused chain may read up to 8 planes per channel (kernels compiled at run time only; cut to the
+ *   "wide" 1 (default): a fused chain may read up to 16 planes per channel (kernels compiled at run time only; cut to the
  *   interpreter's 4 while such a kernel is not there); 0: 4, as before.  Bit-identical either way.
  *   "down2" 0 / 1 (default) / 2: down-sampling with more than 8 taps on both axes runs resize_down2_kernel never / except
  *   where the integer-ratio streaming kernel runs at ratio 4 or 8 / wherever its tables exist (bit-identical; A/B and tests). */
