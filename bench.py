@@ -361,12 +361,13 @@ def main():
             stepfn()
             early += 2
             kc.specialize_wait()
-            if early > 2 and kc.specialize_stats()["kernels_compiled"] == c1:
+            # (with several ranks every rank runs the same number of steps: a step of the fan-in workload exchanges planes)
+            if world == 1 and early > 2 and kc.specialize_stats()["kernels_compiled"] == c1:
                 break
         # The GPU sat idle while hiprtc ran (~2 s for the first program of a process) and its clocks went down with it:
         # when a compile did land, a few more untimed steps bring them back before the timed region (which stays EXACTLY
         # `steps` steps; the JSON reports the requested warm-up count and these extra ones separately).
-        extra = 40 if kc.specialize_stats()["kernels_compiled"] > c0 else 0
+        extra = 40 if (world > 1 or kc.specialize_stats()["kernels_compiled"] > c0) else 0
         extra_warmup[0] += extra
         for _ in range(max(warmup - early, 1 if early else 0) + extra):
             stepfn()
