@@ -150,7 +150,8 @@ KC_API int kc_get_cache_policy(void);
  *   "wide" 1 (default): a fused chain may read up to 16 planes per channel (kernels compiled at run time only; cut to the
  *   interpreter's 4 while such a kernel is not there); 0: 4, as before.  Bit-identical either way.
  *   "down2" 0 / 1 (default) / 2: down-sampling with more than 8 taps on both axes runs resize_down2_kernel never / except
- *   where the integer-ratio streaming kernel runs at ratio 4 or 8 / wherever its tables exist (bit-identical; A/B and tests). */
+ *   where the integer-ratio streaming kernel runs at ratio 4 or 8 / wherever its tables exist (bit-identical; A/B and tests).
+ *   "link_gbps" (153), "hbm_gbps" (6100): the rates kc_live_graph_partition prices a transfer / a streaming kernel with. */
 KC_API int kc_set_option(const char *name, int value);
 KC_API int kc_get_option(const char *name, int *value);
 /* Diagnostics (host only, works without a device): the structure the integer-ratio up-sampling kernels rely on,
@@ -358,16 +359,27 @@ KC_API int kc_live_graph_set_base_dir(kc_live_graph *lg, const char *dir);
  * node on its own thread and needs nothing but the parents' slot data to do so (src/engine.rs:213-275,
  * :288); here the same rule lets independent branches run on different GPUs.  kc_live_graph_partition
  * derives, from the graph alone (so every rank computes the same answer without communicating), which rank
- * evaluates which ancestor of `root` and which slots cross a rank boundary.  The host moves those slots
- * (RCCL send / recv of the planes: kc_plane_device_ptr on the producer's rank, kc_plane_alloc +
- * kc_image_gray / kc_image_rgba on the consumer's) and hands them over with kc_live_graph_import_slot_data;
- * every rank calls kc_live_graph_await_clean only on nodes placed on it.  INTEGRATION.md shows the loop.
+ * evaluates which ancestor of `root` and which slots cross a rank boundary -- or that every rank takes a band of rows.  The
+ * library moves the slots itself (kc_comm_*, kc_live_graph_evaluate_partitioned below); a host with a transport of its own
+ * can do it through kc_plane_device_ptr / kc_plane_alloc + kc_image_gray / kc_image_rgba and kc_live_graph_import_slot_data.
+ * INTEGRATION.md shows both.
  * ========================================================================================== */
 typedef enum kc_partition_policy {
-    KC_PARTITION_AUTO = 0,   /* list scheduling by estimated finish time, transfers charged (one RGBA 4096^2 slot over
-                              * xGMI ~ 12 fused Mix chains): keeps small graphs on one GPU */
-    KC_PARTITION_SPREAD = 1  /* transfers not charged: independent branches fill all ranks */
+    KC_PARTITION_AUTO = 0,   /* the cheapest of {one GPU, branches with transfers charged, row bands + gather of the result},
+                              * priced in one unit (one RGBA 4096^2 slot over xGMI ~ 12 fused Mix chains): small graphs stay
+                              * on one GPU, wide pointwise graphs (BASELINE config #4) go by rows */
+    KC_PARTITION_SPREAD = 1, /* branches, transfers not charged: independent branches fill all ranks */
+    KC_PARTITION_BANDS = 2   /* row bands (KC_ERR_UNSUPPORTED when the band walk does not take the graph or the sources'
+                              * sizes are not known yet) */
 } kc_partition_policy;
+typedef enum kc_plan_kind {
+    KC_PLAN_SINGLE = 0,   /* everything on the home rank, nothing moves */
+    KC_PLAN_BRANCHES = 1, /* nodes placed per rank, `transfers` cross rank boundaries */
+    KC_PLAN_BANDS = 2     /* every rank evaluates rows [y0, y1) of the requested node (kc_partition_bands); the pointwise
+                           * nodes (src/node/mix.rs:136-192) need no exchange at all, the finished bands are gathered on the
+                           * home rank unless kc_partition_set_gather(plan, 0) */
+} kc_plan_kind;
+typedef struct kc_band_range { int32_t y0, y1; } kc_band_range;
 typedef enum kc_node_kind {
     KC_KIND_SOURCE = 0,     /* Embed / Image / Input*: data somebody put there; lives on `rank` */
     KC_KIND_REPLICATED = 1, /* no source among its ancestors (Value nodes and constants built from them):
@@ -385,34 +397,59 @@ KC_API int kc_partition_info(const kc_partition *p, int *world_size, int *home_r
 /* Ancestors of the root (root included) in topological order, with their placement. */
 KC_API int kc_partition_nodes(const kc_partition *p, kc_placement *out, uint32_t cap, uint32_t *count);
 KC_API int kc_partition_transfers(const kc_partition *p, kc_transfer *out, uint32_t cap, uint32_t *count);
+/* Which of the three a plan is, and what KC_PARTITION_AUTO compared (estimated times in units of one fused RGBA Mix chain over
+ * the image; `bands` < 0: no band plan exists).  Any of the out pointers may be NULL. */
+KC_API int kc_partition_kind(const kc_partition *p, int *kind, double *est_single, double *est_branches, double *est_bands);
+/* KC_PLAN_BANDS: the rows of the requested node per rank (`count` = world size) and the node's full size.  A rank holds the rows
+ * kc_live_graph_band_source_rows names for its band of every source (kc_live_graph_embed_slot_data_band), or whole sources. */
+KC_API int kc_partition_bands(const kc_partition *p, kc_band_range *out, uint32_t cap, uint32_t *count, uint32_t *full_width, uint32_t *full_height);
+/* KC_PLAN_BANDS: gather = 0 leaves every rank's band where it is (kc_live_graph_evaluate_partitioned then returns the band on
+ * every rank); the default, 1, assembles the image on the home rank. */
+KC_API int kc_partition_set_gather(kc_partition *p, int gather);
 /* Stores `image` (+1 ref) as slot `slot_id` of `node_id` and marks the node Clean, exactly as the engine does with
  * the result of a finished node (src/engine.rs:34-57): the receiving side of a transfer. */
 KC_API int kc_live_graph_import_slot_data(kc_live_graph *lg, uint32_t node_id, uint32_t slot_id, kc_image *image);
 
-/* The exchange itself: RCCL send / recv of the slots a plan cuts, inside the library (librccl is bound at first use; a
- * process that never calls these needs no RCCL).  One communicator per process:
+/* The exchange itself, inside the library (csrc/comm.cpp): the slots a branch plan cuts, and the finished bands of a band plan,
+ * move between the processes of one node.  Descriptions of slots (size; constant planes travel as scalars, aliased planes once)
+ * go through a shared-memory mailbox, host to host; the planes go over one of two wires, chosen by rank 0 when it makes the id
+ * (environment KC_COMM_TRANSPORT):
+ *   "ipc" (default)  the consumer maps the producer's planes (hipIpcOpenMemHandle), one stream per peer waits ON THE DEVICE for a
+ *                    counter the producer's stream writes behind its kernels, copies (hipMemcpyAsync: the DMA engines over xGMI)
+ *                    and acknowledges the same way; works between processes sharing one GPU too;
+ *   "rccl"           ncclSend / ncclRecv, all transfers of a level in one group (librccl bound at first use; a process that never
+ *                    asks for it needs no RCCL).
+ * No host thread waits for plane data with either.  One communicator per process:
  *   kc_comm_unique_id   rank 0 fills `id` (KC_COMM_ID_BYTES); the host passes it to every rank by whatever channel it has
- *                       (a file, MPI, torch.distributed's store ...);
- *   kc_comm_init        collective over all ranks, after kc_init; a failure is a status (nothing is retried);
- *   kc_live_graph_exchange  works through `transfers` in order -- every rank passes the same list, e.g. what
- *                       kc_partition_transfers returns: the producer's rank evaluates the node (kernels enqueued, nobody
- *                       waits), describes the slot in 64 bytes (size; constant planes travel as scalars, aliased planes once)
- *                       and sends its planes behind an event of the compute stream; a consumer's rank allocates planes,
- *                       receives into them on the communication stream and hands the slot over exactly as
- *                       kc_live_graph_import_slot_data does, the compute stream waiting for the receive.  Consecutive entries
- *                       of one slot are one multi-destination send.  An entry from a rank to itself is legal (the slot is
- *                       replaced by the copy that came back): the one transfer a single-GPU machine can execute.
- *   kc_live_graph_evaluate_partitioned  the whole evaluation: the exchange of `plan`, then `root` on the plan's home rank;
- *                       `*out` (+1 ref) is the root's result there and NULL on the other ranks.
- * The readiness rule that makes this correct is the reference's: a node needs nothing but its parents' slot data
- * (src/engine.rs:213-275). */
+ *                       (a file, a pipe, MPI, torch.distributed's store ...);
+ *   kc_comm_init        collective over all ranks (at most 16), after kc_init; a failure is a status (nothing is retried);
+ *   kc_live_graph_exchange  works through `transfers` level by level -- every rank passes the same list, e.g. what
+ *                       kc_partition_transfers returns; transfers of one level must not depend on each other.  Per level the
+ *                       producer's rank evaluates the node (kernels enqueued, nobody waits) and posts the description; a
+ *                       consumer's rank allocates planes, receives into them and hands the slot over exactly as
+ *                       kc_live_graph_import_slot_data does, its compute stream waiting for the transfer on the device.
+ *                       Consecutive entries of one slot are one multi-destination send.  An entry from a rank to itself is legal
+ *                       (the slot is replaced by the copy that came back).
+ *   kc_comm_gather_bands  every rank passes its band (rows y0 .. of an image `full_height` rows high, e.g. what
+ *                       kc_live_graph_evaluate_band returned); on `home_rank`, `*out` (+1 ref) is the assembled image (the
+ *                       bands must tile it), NULL elsewhere.  Each band travels over its own link, straight to its row offset.
+ *   kc_live_graph_evaluate_partitioned  the whole evaluation of a plan: KC_PLAN_SINGLE / KC_PLAN_BRANCHES -- what this rank can
+ *                       compute before anything arrives is enqueued first (it overlaps the transfers), then the exchange, then
+ *                       `root` on the plan's home rank: `*out` (+1 ref) is the root's result there and NULL on the other ranks;
+ *                       KC_PLAN_BANDS -- this rank's rows of `root`, then the gather (or, after kc_partition_set_gather(plan, 0),
+ *                       `*out` = the band on every rank).
+ * Any failure on any rank makes every host-side wait of every rank fail (they also time out: KC_COMM_TIMEOUT_S seconds, default
+ * 120); the communicator is unusable afterwards.  The readiness rule that makes all this correct is the reference's: a node needs
+ * nothing but its parents' slot data (src/engine.rs:213-275). */
 #define KC_COMM_ID_BYTES 256
 KC_API int kc_comm_unique_id(void *id);
 KC_API int kc_comm_init(int rank, int world_size, const void *id);
 KC_API int kc_comm_destroy(void);
 KC_API int kc_comm_info(int *rank, int *world_size);  /* 0, 0 without a communicator */
+KC_API int kc_comm_transport(char *buf, size_t cap);  /* "ipc", "rccl" or "" */
 KC_API int kc_comm_stats(uint64_t *planes_sent, uint64_t *planes_received, uint64_t *bytes_sent);
 KC_API int kc_live_graph_exchange(kc_live_graph *lg, const kc_transfer *transfers, uint32_t count);
+KC_API int kc_comm_gather_bands(kc_image *band, int32_t y0, uint32_t full_height, int home_rank, kc_image **out);
 KC_API int kc_live_graph_evaluate_partitioned(kc_live_graph *lg, const kc_partition *plan, uint32_t root_node_id, kc_image **out);
 
 /* Row bands: rows [y0, y1) of a node's result without computing the rest -- the data-level way to put several GPUs on one

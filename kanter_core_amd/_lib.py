@@ -39,6 +39,10 @@ class kc_transfer(C.Structure):
                 ("level", C.c_int32)]
 
 
+class kc_band_range(C.Structure):
+    _fields_ = [("y0", C.c_int32), ("y1", C.c_int32)]
+
+
 class kc_band_rows(C.Structure):
     _fields_ = [("node_id", C.c_uint32), ("y0", C.c_int32), ("y1", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32)]
 
@@ -63,6 +67,8 @@ SIGNATURES = {
     "kc_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kc_comm_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kc_live_graph_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "kc_comm_transport": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "kc_comm_gather_bands": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
     "kc_live_graph_evaluate_partitioned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "kc_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "kc_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
@@ -88,6 +94,9 @@ SIGNATURES = {
     "kc_partition_info": (C.c_int, [c_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kc_partition_nodes": (C.c_int, [c_vp, C.POINTER(kc_placement), C.c_uint32, c_u32p]),
     "kc_partition_transfers": (C.c_int, [c_vp, C.POINTER(kc_transfer), C.c_uint32, c_u32p]),
+    "kc_partition_kind": (C.c_int, [c_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "kc_partition_bands": (C.c_int, [c_vp, C.POINTER(kc_band_range), C.c_uint32, c_u32p, c_u32p, c_u32p]),
+    "kc_partition_set_gather": (C.c_int, [c_vp, C.c_int]),
     "kc_live_graph_import_slot_data": (C.c_int, [c_vp, C.c_uint32, C.c_uint32, c_vp]),
     "kc_live_graph_evaluate_band": (C.c_int, [c_vp, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(c_vp)]),
     "kc_live_graph_band_source_rows": (C.c_int, [c_vp, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(kc_band_rows), C.c_uint32, c_u32p]),

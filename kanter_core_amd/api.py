@@ -50,7 +50,7 @@ def _check(status):
     if status != 0:
         L = _lib.load()
         detail = L.kc_last_error() or b""
-        raise TexProError(status, detail.decode(errors="replace") if status >= 100 or status in (3, 14, 18) else "")
+        raise TexProError(status, detail.decode(errors="replace") if status >= 100 or status in (1, 3, 14, 18) else "")
     return status
 
 
@@ -116,7 +116,8 @@ def comm_unique_id():
 
 
 def comm_init(rank, world_size, unique_id):
-    """Collective: this process becomes `rank` of `world_size` in the library's RCCL communicator (after init())."""
+    """Collective: this process becomes `rank` of `world_size` in the library's communicator (after init()): a shared-memory
+    mailbox plus the wire rank 0 chose when it made the id ("ipc" by default, KC_COMM_TRANSPORT=rccl for RCCL)."""
     assert len(unique_id) == COMM_ID_BYTES
     _check(_lib.load().kc_comm_init(int(rank), int(world_size), C.create_string_buffer(unique_id, COMM_ID_BYTES)))
 
@@ -129,6 +130,21 @@ def comm_info():
     r, w = C.c_int(), C.c_int()
     _check(_lib.load().kc_comm_info(C.byref(r), C.byref(w)))
     return r.value, w.value
+
+
+def comm_transport():
+    """"ipc", "rccl" or "" (no communicator)."""
+    buf = C.create_string_buffer(16)
+    _check(_lib.load().kc_comm_transport(buf, len(buf)))
+    return buf.value.decode()
+
+
+def comm_gather_bands(band, y0, full_height, home_rank=0):
+    """Every rank passes its band (a SlotImage holding rows y0 .. of a `full_height`-row image); the assembled SlotImage on
+    `home_rank`, None elsewhere (csrc/comm.cpp)."""
+    out = C.c_void_p()
+    _check(_lib.load().kc_comm_gather_bands(band._h, int(y0), int(full_height), int(home_rank), C.byref(out)))
+    return SlotImage(out.value) if out.value else None
 
 
 def comm_stats():
@@ -236,6 +252,11 @@ def stats():
     d = C.c_uint64()
     _check(_lib.load().kc_stats_algorithmic_bytes(C.byref(d)))
     return {"bytes_in_use": a.value, "bytes_cached": b.value, "kernel_launches": c.value, "algorithmic_bytes": d.value}
+
+
+def pool_trim():
+    """kc_pool_trim: waits for the stream and gives every cached (free) block back to the driver."""
+    _check(_lib.load().kc_pool_trim())
 
 
 def stats_counter(name):
@@ -946,7 +967,7 @@ class LiveGraph:
 
     def partition(self, root_node_id, world_size, policy=0):
         """Multi-GPU placement of the evaluation of `root_node_id` over `world_size` ranks (csrc/partition.cpp);
-        the same on every rank.  policy: PartitionPolicy.Auto / .Spread."""
+        the same on every rank.  policy: PartitionPolicy.Auto / .Spread / .Bands."""
         h = C.c_void_p()
         _check(_lib.load().kc_live_graph_partition(self._h, int(root_node_id), int(world_size), int(policy), C.byref(h)))
         return Partition(h.value)
@@ -986,7 +1007,8 @@ class LiveGraph:
 
     def evaluate_partitioned(self, plan, root_node_id):
         """The exchange of `plan` (a Partition) followed by `root_node_id` on the plan's home rank: the root's image there,
-        None on the other ranks."""
+        None on the other ranks.  A band plan: this rank's rows, gathered on the home rank (or, after plan.set_gather(False),
+        the band itself on every rank)."""
         out = C.c_void_p()
         _check(_lib.load().kc_live_graph_evaluate_partitioned(self._h, plan._h, int(root_node_id), C.byref(out)))
         return SlotImage(out.value) if out.value else None
@@ -1001,7 +1023,11 @@ class LiveGraph:
 
 
 class PartitionPolicy:
-    Auto, Spread = 0, 1
+    Auto, Spread, Bands = 0, 1, 2
+
+
+class PlanKind:
+    Single, Branches, Bands = 0, 1, 2
 
 
 class NodeKind:
@@ -1029,6 +1055,23 @@ class Partition:
         tb = (kc_transfer * max(n.value, 1))()
         _check(L.kc_partition_transfers(self._h, tb, n.value, C.byref(n)))
         self.transfers = [(tb[i].node_id, tb[i].slot_id, tb[i].src_rank, tb[i].dst_rank, tb[i].level) for i in range(n.value)]
+        k, a, b, c = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        _check(L.kc_partition_kind(self._h, C.byref(k), C.byref(a), C.byref(b), C.byref(c)))
+        # kind: PlanKind; estimates: what PartitionPolicy.Auto compared, in units of one fused RGBA Mix chain over the image
+        self.kind, self.estimates = k.value, {"single": a.value, "branches": b.value, "bands": c.value if c.value >= 0 else None}
+        from ._lib import kc_band_range
+        fw, fh = C.c_uint32(), C.c_uint32()
+        _check(L.kc_partition_bands(self._h, None, 0, C.byref(n), C.byref(fw), C.byref(fh)))
+        bb = (kc_band_range * max(n.value, 1))()
+        _check(L.kc_partition_bands(self._h, bb, n.value, C.byref(n), C.byref(fw), C.byref(fh)))
+        self.bands = [(bb[i].y0, bb[i].y1) for i in range(n.value)]  # PlanKind.Bands: rows of the requested node per rank
+        self.full_size = (fw.value, fh.value)
+        self.gather = True
+
+    def set_gather(self, gather):
+        """PlanKind.Bands: False leaves every rank's band where it is (evaluate_partitioned returns the band everywhere)."""
+        _check(_lib.load().kc_partition_set_gather(self._h, int(bool(gather))))
+        self.gather = bool(gather)
 
     def __del__(self):
         try:

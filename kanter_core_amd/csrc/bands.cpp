@@ -728,6 +728,27 @@ int band_source_rows(kc_live_graph &lg0, uint32_t root, int32_t y0, int32_t y1, 
     return KC_OK;
 }
 
+// What a row-band PLAN needs (partition.cpp): is the graph one the band walk takes, and how large is the requested node's image?
+int band_plan_info(kc_live_graph &lg0, uint32_t root, kc_size *size, bool *rgba)
+{
+    if (!lg0.g.find(root)) return KC_ERR_INVALID_NODE_ID;
+    std::unique_ptr<kc_live_graph> flat;
+    uint32_t slot = 0;
+    if (lg0.g.find(root)->type == KC_NODE_GRAPH) {
+        const std::vector<uint32_t> outs = lg0.g.find(root)->graph ? lg0.g.find(root)->graph->output_ids() : std::vector<uint32_t>{};
+        if (outs.empty()) return KC_ERR_NO_SLOT_DATA;
+        slot = outs[0];
+    }
+    KC_TRY(expand_graph_nodes(lg0, &root, &slot, flat));
+    kc_live_graph &lg = flat ? *flat : lg0;
+    Walk W(lg);
+    KC_TRY(topo_order(lg.g, root, W.topo));
+    KC_TRY(infer_sizes(W));
+    *size = W.size[root];
+    *rgba = W.rgba[root];
+    return KC_OK;
+}
+
 int band_evaluate(kc_live_graph &lg0, uint32_t root, uint32_t slot, int32_t y0, int32_t y1, kc_image **out)
 {
     *out = nullptr;

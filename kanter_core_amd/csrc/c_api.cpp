@@ -238,6 +238,8 @@ try {
     else if (std::strcmp(name, "join") == 0) ctx().join = value != 0;
     else if (std::strcmp(name, "wide") == 0) ctx().wide = value != 0;
     else if (std::strcmp(name, "down2") == 0 && value >= 0 && value <= 2) ctx().down2 = value;
+    else if (std::strcmp(name, "link_gbps") == 0 && value > 0) ctx().link_gbps = value;
+    else if (std::strcmp(name, "hbm_gbps") == 0 && value > 0) ctx().hbm_gbps = value;
     else {
         set_error(std::string("unknown option ") + name);
         return KC_ERR_INVALID_ARG;
@@ -254,6 +256,8 @@ try {
     else if (std::strcmp(name, "join") == 0) *value = ctx().join ? 1 : 0;
     else if (std::strcmp(name, "wide") == 0) *value = ctx().wide ? 1 : 0;
     else if (std::strcmp(name, "down2") == 0) *value = ctx().down2;
+    else if (std::strcmp(name, "link_gbps") == 0) *value = ctx().link_gbps;
+    else if (std::strcmp(name, "hbm_gbps") == 0) *value = ctx().hbm_gbps;
     else {
         set_error(std::string("unknown option ") + name);
         return KC_ERR_INVALID_ARG;
@@ -1393,6 +1397,36 @@ try {
 }
 KC_CATCH
 
+int kc_partition_kind(const kc_partition *p, int *kind, double *est_single, double *est_branches, double *est_bands)
+try {
+    KC_ARG(p);
+    if (kind) *kind = p->kind;
+    if (est_single) *est_single = p->est_single;
+    if (est_branches) *est_branches = p->est_branches;
+    if (est_bands) *est_bands = p->est_bands;
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_partition_bands(const kc_partition *p, kc_band_range *out, uint32_t cap, uint32_t *count, uint32_t *full_width, uint32_t *full_height)
+try {
+    KC_ARG(p && count);
+    *count = (uint32_t)p->bands.size();
+    for (uint32_t i = 0; out && i < cap && i < *count; ++i) out[i] = p->bands[i];
+    if (full_width) *full_width = p->full_w;
+    if (full_height) *full_height = p->full_h;
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_partition_set_gather(kc_partition *p, int gather)
+try {
+    KC_ARG(p);
+    p->gather = gather != 0;
+    return KC_OK;
+}
+KC_CATCH
+
 int kc_comm_unique_id(void *id)
 try {
     return comm_unique_id(id, KC_COMM_ID_BYTES);
@@ -1426,6 +1460,23 @@ try {
     Lock lk(ctx().mu);
     comm_stats(planes_sent, planes_received, bytes_sent);
     return KC_OK;
+}
+KC_CATCH
+
+int kc_comm_transport(char *buf, size_t cap)
+try {
+    Lock lk(ctx().mu);
+    KC_ARG(buf && cap > 0);
+    std::snprintf(buf, cap, "%s", comm_wire_name());
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_comm_gather_bands(kc_image *band, int32_t y0, uint32_t full_height, int home_rank, kc_image **out)
+try {
+    Lock lk(ctx().mu);
+    KC_ARG(band && out);
+    return comm_gather_bands(band, y0, full_height, home_rank, out);
 }
 KC_CATCH
 

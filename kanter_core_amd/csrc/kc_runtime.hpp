@@ -228,6 +228,8 @@ struct Context {
     bool wide = true;    // chains of up to KC_CHAIN_MAX_IN input planes (compiled kernels only); 0: KC_CHAIN_INTERP_IN as before (kc_set_option("wide"); env KC_WIDE)
     bool join = true;    // a Mix of two unevaluated chains keeps both in one program (kc_set_option("join", 0); env KC_JOIN)
     bool chain1 = true;  // one-step programs run the ahead-of-time kernels of chain1.hip (kc_set_option("chain1", 0): interpreter / specialiser, A/B and tests)
+    int link_gbps = 153;   // one xGMI link, what the planner charges a transfer with (kc_set_option("link_gbps"))
+    int hbm_gbps = 6100;   // what a streaming kernel gets from HBM with nothing in the Infinity Cache (kc_set_option("hbm_gbps"))
     int cache_policy = 1;  // 1: launches whose streams exceed the Infinity Cache mark them nontemporal (cache_policy_mask); 0: plain loads / stores (KC_CACHE_POLICY, kc_set_cache_policy)
     int max_blocks = 4096;
     int chain_unroll = 0;  // float4 per thread per decode in the chain kernel; 0 = heuristic (KC_CHAIN_UNROLL)
@@ -266,6 +268,7 @@ struct ResizeMemoScope {
 
 Context &ctx();
 void set_error(const std::string &msg);
+const std::string &last_error();
 int hip_fail(hipError_t e, const char *what);  // records the message, returns KC_ERR_HIP
 int need_init();                               // KC_OK or KC_ERR_NO_DEVICE
 
@@ -599,21 +602,28 @@ struct kc_live_graph {
 // Multi-GPU placement plan (partition.cpp)
 struct kc_partition {
     int world = 1, home = 0, n_levels = 1;
+    int kind = KC_PLAN_BRANCHES;
+    bool gather = true;  // KC_PLAN_BANDS: the bands end on the home rank (kc_partition_set_gather)
+    uint32_t root = 0;
     std::vector<kc_placement> nodes;  // topological order
     std::vector<kc_transfer> xfers;   // execution order: level, producer's topological position, slot, destination
+    std::vector<kc_band_range> bands;  // KC_PLAN_BANDS: rows [y0, y1) of the requested node per rank
+    uint32_t full_w = 0, full_h = 0;
+    double est_single = 0.0, est_branches = 0.0, est_bands = -1.0;  // what KC_PARTITION_AUTO compared (partition.cpp)
 };
 
 namespace kc {
 // Row-band evaluation (bands.cpp)
 int band_evaluate(kc_live_graph &lg, uint32_t root, uint32_t slot, int32_t y0, int32_t y1, kc_image **out);
 int band_source_rows(kc_live_graph &lg, uint32_t root, int32_t y0, int32_t y1, std::vector<kc_band_rows> &out);
-int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out);
+int partition_plan(kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out);
+int band_plan_info(kc_live_graph &lg, uint32_t root, kc_size *size, bool *rgba);  // the requested node's logical size, if the band walk takes the graph
 // Replay of a recorded evaluation (replay.cpp)
 struct ReplayRecorder;
 int replay_try(kc_live_graph &lg, uint32_t id, bool *hit);
 ReplayRecorder *replay_begin(kc_live_graph &lg, uint32_t id);
 void replay_end(kc_live_graph &lg, uint32_t id, ReplayRecorder *r, int s);
-// The exchange (comm.cpp): RCCL, bound at first use.  Callers hold the context lock.
+// The exchange (comm.cpp): a shared-memory mailbox + IPC copies or RCCL.  Callers hold the context lock.
 int comm_unique_id(void *id, size_t bytes);
 int comm_init(int rank, int world, const void *id, size_t bytes);
 int comm_destroy();
@@ -621,6 +631,9 @@ void comm_info(int *rank, int *world);
 void comm_stats(uint64_t *planes_sent, uint64_t *planes_received, uint64_t *bytes_sent);
 int comm_exchange(kc_live_graph &lg, const kc_transfer *t, uint32_t n);
 int comm_evaluate_partitioned(kc_live_graph &lg, const kc_partition &plan, uint32_t root, kc_image **out);
+int comm_gather_bands(kc_image *band, int32_t y0, uint32_t full_h, int home, kc_image **out);
+const char *comm_wire_name();
+void comm_blocks_freed();  // kc_pool_trim has given blocks back to the driver
 void comm_sync();
 // process_node, src/node/node_type.rs:213-248: inputs in edge insertion order.
 int process_node(kc_live_graph &lg, const Node &node, const SlotList &inputs, const std::vector<kc_edge> &edges,

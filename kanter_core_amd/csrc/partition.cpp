@@ -25,6 +25,20 @@
 //   5. sources live on the lowest rank that consumes them; every other edge from a non-replicated producer to a
 //      consumer on another rank is a transfer.  One slot consumed on several ranks appears once per
 //      destination, consecutively: a broadcast.
+//
+// The other way to use several GPUs is by ROWS (bands.cpp): every rank evaluates the whole graph for its band of the requested
+// node -- pointwise nodes (src/node/mix.rs:136-192) need nothing from the other bands, a resize or HeightToNormal a few halo rows,
+// computed redundantly -- and the only data that moves is the finished band, to the home rank's row offset (comm.cpp,
+// comm_gather_bands): (world - 1) transfers of 1 / world of the result, each over its own xGMI link.  A plan of kind
+// KC_PLAN_BANDS says which rows each rank takes.  KC_PARTITION_AUTO prices the three possibilities in the same unit (one fused
+// RGBA Mix chain over the image = 40 B/px at the HBM rate; one RGBA slot over one link = 12 B/px at the link rate, 12 such units
+// with the default rates) and takes the cheapest:
+//     one GPU    sum of the node weights
+//     branches   the list schedule's finish time, transfers charged (above)
+//     bands      (sum of the node weights) / world  +  (transfer of the result) / world
+// Config #4 (eight 16-node branches + add tree at 4096 x 4096, 8 GPUs): 8.4 / 53 / 2.6 units -> bands; on 2 GPUs 8.4 / 15 / 10.2
+// -> one GPU.  A linear chain whose result must end on one GPU never pays (the result's transfer alone costs more than the
+// chain): kc_partition_set_gather(plan, 0) leaves the bands where they are, for consumers that are row-parallel too.
 #include <algorithm>
 
 #include "kc_runtime.hpp"
@@ -51,18 +65,25 @@ double node_weight(const Node &n, bool use_cache)
     }
 }
 
-const double kTransferCost = 12.0;  // one RGBA slot over one xGMI link, in the units of node_weight
+// one RGBA slot (three planes: Mix never reads the producer's alpha) over one xGMI link, in the units of node_weight:
+// (12 B/px / link rate) / (40 B/px / HBM rate); 11.96 with the default 153 GB/s and 6.1 TB/s (kc_set_option "link_gbps" / "hbm_gbps")
+double transfer_cost()
+{
+    const Context &c = ctx();
+    return 0.3 * (double)c.hbm_gbps / (double)std::max(c.link_gbps, 1);
+}
 
 }  // namespace
 
-int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out)
+int partition_plan(kc_live_graph &lg, uint32_t root, int world, int policy, kc_partition **out)
 {
     const NodeGraph &g = lg.g;
     if (!g.find(root)) return KC_ERR_INVALID_NODE_ID;
-    if (world < 1 || world > 1024 || (policy != KC_PARTITION_AUTO && policy != KC_PARTITION_SPREAD)) {
-        set_error("partition: world must be 1..1024 and policy KC_PARTITION_AUTO or KC_PARTITION_SPREAD");
+    if (world < 1 || world > 1024 || (policy != KC_PARTITION_AUTO && policy != KC_PARTITION_SPREAD && policy != KC_PARTITION_BANDS)) {
+        set_error("partition: world must be 1..1024 and policy KC_PARTITION_AUTO, KC_PARTITION_SPREAD or KC_PARTITION_BANDS");
         return KC_ERR_INVALID_ARG;
     }
+    const double kTransferCost = transfer_cost();
     // ---- 1. ancestors in topological order (iterative post-order; an edge into the stack is a cycle)
     std::vector<uint32_t> topo;
     std::map<uint32_t, int> mark;  // 1 = on the stack, 2 = done
@@ -219,6 +240,16 @@ int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy
         for (size_t c : consumers(i)) r = r < 0 ? rank[c] : std::min(r, rank[c]);
         rank[i] = r < 0 ? home : r;  // a source nobody computes on is the requested node itself
     }
+    // levels again, now that the sources have their ranks: a component that reads a source held by another rank runs after that
+    // transfer (level 0), so what it sends is level 1 -- the transfers of one level never depend on each other (comm.cpp works
+    // through a level's sends before its receives).  Components are numbered in topological order.
+    for (auto &c : comps) {
+        c.level = 0;
+        for (int i : c.inputs) c.level = std::max(c.level, comps[i].level + (comps[i].rank == c.rank ? 0 : 1));
+        for (size_t m : c.members)
+            for (uint32_t p : g.get_parents(topo[m]))
+                if (needed(p) && kind[pos[p]] == SOURCE && rank[pos[p]] != c.rank) c.level = std::max(c.level, 1);
+    }
     kc_partition *P = new kc_partition();
     P->world = world;
     P->home = home;
@@ -246,6 +277,54 @@ int partition_plan(const kc_live_graph &lg, uint32_t root, int world, int policy
     }
     for (auto &k : seen) P->xfers.push_back(kc_transfer{ topo[k.ppos], k.slot, rank[k.ppos], k.dst, k.level });
     P->n_levels = std::max(levels, 1);
+    P->root = root;
+
+    // ---- 6. one GPU, branches or row bands
+    double single = 0.0, branches = 0.0;
+    for (auto &c : comps) {
+        single += std::max(c.weight, 1.0 / 64.0);
+        branches = std::max(branches, c.finish);
+    }
+    bool all_home = P->xfers.empty();
+    for (size_t i = 0; i < n; ++i) all_home &= kind[i] != COMPUTE || rank[i] == home;
+    P->kind = all_home ? KC_PLAN_SINGLE : KC_PLAN_BRANCHES;
+    P->est_single = single;
+    P->est_branches = all_home ? single : branches;
+    // bands need the requested node's height (every rank must cut the same rows) and a graph the band walk can take
+    kc_size rsize{ 0, 0 };
+    bool rrgba = true;
+    std::string band_error;
+    bool bands_ok = false;
+    if (world > 1) {
+        const std::string saved = last_error();
+        bands_ok = band_plan_info(lg, root, &rsize, &rrgba) == KC_OK && rsize.height >= (uint32_t)world;
+        if (!bands_ok) band_error = rsize.height && rsize.height < (uint32_t)world ? "fewer rows than ranks" : last_error();
+        set_error(saved);
+    }
+    P->est_bands = bands_ok ? single / world + kTransferCost * (rrgba ? 1.0 : 1.0 / 3.0) / world : -1.0;
+    if (policy == KC_PARTITION_BANDS && !bands_ok) {
+        delete P;
+        set_error("partition: no row-band plan for this graph (" + (world == 1 ? std::string("one rank") : band_error) +
+                  "); sources must be embedded, whole or as constant placeholders of their size, before the plan is made");
+        return KC_ERR_UNSUPPORTED;
+    }
+    if (bands_ok && (policy == KC_PARTITION_BANDS || (policy == KC_PARTITION_AUTO && P->est_bands < P->est_branches - 1e-9))) {
+        P->kind = KC_PLAN_BANDS;
+        P->xfers.clear();
+        P->n_levels = 1;
+        for (auto &pl : P->nodes) {
+            pl.rank = -1;  // every rank: its rows
+            pl.component = -1;
+        }
+        P->full_h = rsize.height;
+        P->full_w = rsize.width;
+        uint32_t start = 0;
+        for (int r = 0; r < world; ++r) {
+            const uint32_t rows = rsize.height / (uint32_t)world + ((uint32_t)r < rsize.height % (uint32_t)world ? 1u : 0u);
+            P->bands.push_back(kc_band_range{ (int32_t)start, (int32_t)(start + rows) });
+            start += rows;
+        }
+    }
     *out = P;
     return KC_OK;
 }

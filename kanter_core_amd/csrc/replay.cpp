@@ -202,7 +202,19 @@ struct ReplayRecorder {
     ReplayCapture cap;
     uint64_t launches0 = 0;
     std::unordered_set<uint32_t> changed0;
+    // The planes of the held images (slot data, embedded images) that were RESIDENT when the recording began, by address: the
+    // only planes a recorded launch may read from outside the sequence.  The entry's reference on the image keeps exactly those
+    // blocks alive.  An embedded image that is still an unevaluated chain or a deferred resize (mix_process / as_type / resize
+    // results can be embedded) reads the operands of ITS chain, which only its links hold: forced from outside between two
+    // evaluations they go back to the pool and a replay would launch on recycled addresses.
+    std::set<const void *> resident0;
 };
+
+static void note_resident(std::set<const void *> &set, const kc_image *img)
+{
+    for (int p = 0; p < img->n; ++p)
+        if (img->planes[p]->kind == kc_plane::MEM) set.insert(img->planes[p]->dptr);
+}
 
 ReplayRecorder *replay_begin(kc_live_graph &lg, uint32_t id)
 {
@@ -220,6 +232,7 @@ ReplayRecorder *replay_begin(kc_live_graph &lg, uint32_t id)
             if (sd.node_id == id) continue;  // the requested node's previous result: replaced, never read
             image_retain(sd.image);
             e->pre_slots.push_back({ sd.node_id, sd.slot_id, sd.image });
+            note_resident(r->resident0, sd.image);
         }
     for (auto &em : lg.embedded) {
         if (em.full_h != 0) {  // row-band sources: another evaluation path
@@ -229,6 +242,7 @@ ReplayRecorder *replay_begin(kc_live_graph &lg, uint32_t id)
         }
         image_retain(em.image);
         e->embedded.push_back(em);
+        note_resident(r->resident0, em.image);
     }
     r->launches0 = c.launches;
     r->changed0 = lg.changed;
@@ -330,6 +344,8 @@ void replay_end(kc_live_graph &lg, uint32_t id, ReplayRecorder *r, int s)
                             L.in_from[b][k] = (int)lj;
                             L.in_ch[b][k] = bj;
                         }
+                // anything else must be a plane the entry itself keeps alive (see ReplayRecorder::resident0)
+                if (L.in_from[b][k] < 0 && !r->resident0.count(L.prog.in[b][k])) return;
             }
     }
     for (uint32_t ch : lg.changed)

@@ -185,6 +185,7 @@ int pool_trim()
     std::lock_guard<std::recursive_mutex> lk(c.mu);
     if (c.stream) (void)hipStreamSynchronize(c.stream);
     for (auto &kv : c.free_blocks) (void)hipFree(kv.second);
+    if (!c.free_blocks.empty()) comm_blocks_freed();  // peers of a communicator must not keep freed blocks mapped
     c.free_blocks.clear();
     c.bytes_cached = 0;
     return KC_OK;

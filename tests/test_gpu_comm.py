@@ -1,9 +1,9 @@
-"""The exchange behind the C ABI (csrc/comm.cpp: kc_comm_init, kc_live_graph_exchange, kc_live_graph_evaluate_partitioned)
-executed with RCCL on the one GPU a test box has: a world of one rank whose transfers go from rank 0 to rank 0 (RCCL
-allows a send to self inside a group).  Every part of the path runs -- the 64-byte slot description on its own
-communicator and stream, plane data behind an event of the compute stream, constant planes as scalars, aliased planes
-once, caller-owned planes through a dense copy, the import on the receiving side -- and what comes back must be the
-oracle's result bit for bit.  The N-rank plans themselves are covered over gloo (tests/test_multi_gpu_gloo.py)."""
+"""The exchange behind the C ABI (csrc/comm.cpp: kc_comm_init, kc_live_graph_exchange, kc_live_graph_evaluate_partitioned) in a
+world of ONE rank whose transfers go from rank 0 to rank 0, over both wires (RCCL allows a send to self inside a group; the IPC
+wire reads its own planes directly).  Every part of the path runs -- the slot description through the mailbox, plane data
+behind the compute stream, constant planes as scalars, aliased planes once, caller-owned planes through a dense copy, the
+import on the receiving side -- and what comes back must be the oracle's result bit for bit.  Several ranks:
+tests/test_gpu_comm_ranks.py (processes sharing the GPU); the plans themselves on CPU: tests/test_multi_gpu_gloo.py."""
 import json
 
 import numpy as np
@@ -16,15 +16,21 @@ from util import SEED_A, SEED_B, assert_planes, bit_equal, splitmix_plane
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def kc():
+@pytest.fixture(scope="module", params=["ipc", "rccl"])
+def kc(request):
+    """Both wires: the IPC one reads its own planes directly when a rank sends to itself, RCCL sends to self inside a group."""
+    import os
     import kanter_core_amd as kc
     kc.init(0)
-    kc.comm_init(0, 1, kc.comm_unique_id())
-    assert kc.comm_info() == (0, 1)
+    os.environ["KC_COMM_TRANSPORT"] = request.param
+    try:
+        kc.comm_init(0, 1, kc.comm_unique_id())
+    finally:
+        del os.environ["KC_COMM_TRANSPORT"]
+    assert kc.comm_info() == (0, 1) and kc.comm_transport() == request.param
     yield kc
     kc.comm_destroy()
-    assert kc.comm_info() == (0, 0)
+    assert kc.comm_info() == (0, 0) and kc.comm_transport() == ""
 
 
 @pytest.fixture(scope="module")

@@ -1,0 +1,136 @@
+"""The native N > 1 path (csrc/comm.cpp: mailbox + IPC wire, kc_live_graph_evaluate_partitioned, kc_comm_gather_bands) run by
+2 and 3 PROCESSES that share the one GPU of a test box -- the same control flow, streams, counters and copies that run with
+one process per GPU on a multi-GPU node.  Every rank holds only the data its plan gives it (everything else is a NaN
+placeholder of the right size), and what ends up on the home rank must be the oracle's result bit for bit.
+Plans: branches (BASELINE config #4's partitioned form, the diamond / fan-in / broadcast graphs), row bands + gather
+(config #4 as KC_PARTITION_AUTO runs it on 3+ GPUs; a graph with a resize and a HeightToNormal in its branches), one GPU."""
+import numpy as np
+import pytest
+
+from rank_harness import run_ranks, run_ranks_expect_failure
+from rank_scenarios import case, source_planes
+from util import splitmix_plane
+
+pytestmark = pytest.mark.gpu
+
+_oracle_cache = {}
+
+
+def oracle_result(name, h, w):
+    key = (name, h, w)
+    if key not in _oracle_cache:
+        from oracle import oracle as orc
+        orc.set_threads(8)
+        graph, root, sizes = case(name, h, w)
+        emb = {eid: orc.Image(source_planes(eid, size)) for eid, size in sizes.items()}
+        _oracle_cache[key] = [np.ascontiguousarray(p).tobytes() for p in orc.RefGraph(graph, embedded=emb).slot_data(root, 0).image.planes]
+        orc.set_threads(1)
+    return _oracle_cache[key]
+
+
+def check_home_result(outs, want, what):
+    home = outs[0]["home"]
+    for r, o in enumerate(outs):
+        for rep, planes in enumerate(o["outs"]):
+            if r == home:
+                assert planes is not None and len(planes) == len(want)
+                for c, (g, x) in enumerate(zip(planes, want)):
+                    if g != x:
+                        ga, xa = np.frombuffer(g, np.uint32), np.frombuffer(x, np.uint32)
+                        raise AssertionError("%s: rank %d, evaluation %d, channel %d: %d of %d pixels differ from the oracle"
+                                             % (what, r, rep, c, int((ga != xa).sum()), ga.size))
+            else:
+                assert planes is None
+
+
+@pytest.mark.parametrize("world,name", [(2, "diamond"), (3, "diamond"), (2, "fanin"), (3, "fanin")])
+def test_branch_plans_between_processes(world, name):
+    import kanter_core_amd as kc
+    outs = run_ranks(world, "evaluate_plan", name=name, h=20, w=24, policy=kc.PartitionPolicy.Spread)
+    assert all(o["kind"] == kc.PlanKind.Branches and o["transport"] == "ipc" for o in outs)
+    assert all(o["transfers"] == outs[0]["transfers"] for o in outs) and outs[0]["transfers"]
+    check_home_result(outs, oracle_result(name, 20, 24), "%s over %d ranks" % (name, world))
+    sent, recv = sum(o["stats"]["planes_sent"] for o in outs), sum(o["stats"]["planes_received"] for o in outs)
+    assert sent == recv and sent >= 2 * len(outs[0]["transfers"])  # two evaluations
+    assert outs[outs[0]["home"]]["mappings"] > 0  # the home rank really mapped its peers' planes
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config4_by_branches_512(world):
+    import kanter_core_amd as kc
+    outs = run_ranks(world, "evaluate_plan", name="config4", h=512, w=512, policy=kc.PartitionPolicy.Spread)
+    assert all(o["kind"] == kc.PlanKind.Branches for o in outs)
+    # every branch that is not on the home rank travels once per evaluation, three planes (alpha = 1 goes as a scalar)
+    assert sum(o["stats"]["planes_received"] for o in outs) == 2 * 3 * len(outs[0]["transfers"])
+    check_home_result(outs, oracle_result("config4", 512, 512), "config #4 by branches, %d ranks" % world)
+
+
+@pytest.mark.parametrize("world,specialize", [(2, None), (3, None), (3, 2)])
+def test_config4_by_row_bands_512(world, specialize):
+    import kanter_core_amd as kc
+    outs = run_ranks(world, "evaluate_plan", name="config4", h=512, w=512, policy=kc.PartitionPolicy.Bands, specialize=specialize)
+    assert all(o["kind"] == kc.PlanKind.Bands and not o["transfers"] for o in outs)
+    bands = outs[0]["bands"]
+    assert bands[0][0] == 0 and bands[-1][1] == 512 and all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+    # only the finished bands move: three planes per remote rank and evaluation
+    assert sum(o["stats"]["planes_received"] for o in outs) == 2 * 3 * (world - 1)
+    check_home_result(outs, oracle_result("config4", 512, 512), "config #4 by row bands, %d ranks" % world)
+
+
+def test_auto_keeps_config4_on_one_gpu_with_two_ranks_and_takes_bands_with_three():
+    import kanter_core_amd as kc
+    want = oracle_result("config4", 128, 128)
+    outs = run_ranks(2, "evaluate_plan", name="config4", h=128, w=128, policy=kc.PartitionPolicy.Auto)
+    assert all(o["kind"] == kc.PlanKind.Single for o in outs), outs[0]["estimates"]
+    assert sum(o["stats"]["planes_received"] for o in outs) == 0
+    check_home_result(outs, want, "config #4, auto, 2 ranks")
+    outs = run_ranks(3, "evaluate_plan", name="config4", h=128, w=128, policy=kc.PartitionPolicy.Auto)
+    assert all(o["kind"] == kc.PlanKind.Bands for o in outs), outs[0]["estimates"]
+    est = outs[0]["estimates"]
+    assert est["bands"] < est["single"] <= est["branches"]
+    check_home_result(outs, want, "config #4, auto, 3 ranks")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bands_of_a_graph_with_resize_and_height_to_normal(world):
+    """One branch up-samples a half-size source, another ends in HeightToNormal: the bands carry halo rows (the first band
+    the image's LAST row), every rank embeds exactly the rows kc_live_graph_band_source_rows names."""
+    import kanter_core_amd as kc
+    h, w = 96, 80
+    want = oracle_result("config4_resize_h2n", h, w)
+    outs = run_ranks(world, "evaluate_plan", name="config4_resize_h2n", h=h, w=w, policy=kc.PartitionPolicy.Bands)
+    check_home_result(outs, want, "resize + h2n by bands, %d ranks" % world)
+    # without the gather every rank keeps its rows
+    outs = run_ranks(world, "evaluate_plan", name="config4_resize_h2n", h=h, w=w, policy=kc.PartitionPolicy.Bands, gather=False, reps=1)
+    pitch = w * 4
+    for r, o in enumerate(outs):
+        y0, y1 = o["bands"][r]
+        assert [p == x[y0 * pitch:y1 * pitch] for p, x in zip(o["outs"][0], want)] == [True] * len(want)
+        assert o["stats"]["planes_sent"] == 0
+
+
+@pytest.mark.parametrize("gray,home", [(True, 0), (False, 1), (False, 2)])
+def test_gather_of_uneven_bands(gray, home):
+    h, w = 37, 50
+    outs = run_ranks(3, "gather_direct", h=h, w=w, cuts=[0, 1, 20, 37], gray=gray, home=home)
+    full = [splitmix_plane(0x5EED0777, c, h, w) for c in range(1 if gray else 4)]
+    for rep in range(2):
+        want = [(p + np.float32(rep)) for p in full]
+        if not gray:
+            want = [(x + np.float32(0.0)) for x in want[:3]] + [np.ones((h, w), np.float32)]
+        got = outs[home]["outs"][rep]
+        assert [g == x.tobytes() for g, x in zip(got, want)] == [True] * len(want)
+        assert all(o["outs"][rep] is None for r, o in enumerate(outs) if r != home)
+    assert outs[home]["mappings"] >= 2 * (1 if gray else 3)  # after the trim the freed blocks were mapped afresh
+
+
+def test_a_failing_rank_fails_its_peers_instead_of_hanging_them():
+    res = run_ranks_expect_failure(2, "mismatched_lists")
+    assert res[1][0] == "error" and "outside the communicator" in res[1][1]
+    assert res[0][0] == "error" and ("another rank reported a failure" in res[0][1] or "timed out" in res[0][1])
+
+
+def test_a_silent_peer_is_a_timeout_not_a_hang():
+    res = run_ranks_expect_failure(2, "silent_peer")
+    assert res[0][0] == "error" and "timed out" in res[0][1]
+    assert res[1][0] == "ok"

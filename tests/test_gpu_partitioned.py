@@ -1,10 +1,10 @@
-"""Partitioned (multi-rank) evaluation on the device: the exchange loop of multi_gpu.PartitionedEvaluator with the
-library as slot store (planes exported / imported as torch views of the library's pitched HBM buffers).
+"""Partitioned (multi-rank) evaluation on the device through multi_gpu.PartitionedEvaluator as a torch.distributed program
+uses it: the process group (gloo here) only carries the communicator's identifier; the exchange is the library's
+(csrc/comm.cpp, IPC wire).
   * world = 1: the partitioned path is the plain evaluation; result == oracle.
-  * world = 2 and 3 on ONE GPU: the processes all bound to cuda:0, planes staged through the host over gloo -- a
-    rehearsal of the RCCL path (RCCL refuses two ranks on one device); the home rank's result == oracle, and
-    the second round (imports replace the previous round's slots) too.
-The real N-GPU run is the driver's (bench.py --gpus N); see tests/test_multi_gpu_gloo.py for the plan itself."""
+  * world = 2 and 3 on ONE GPU: the processes all bound to cuda:0; the home rank's result == oracle, and the second round
+    (imports replace the previous round's slots) too.
+tests/test_gpu_comm_ranks.py drives the same path without torch.distributed; tests/test_multi_gpu_gloo.py the plans on CPU."""
 import json
 import os
 
@@ -82,6 +82,9 @@ def _worker(rank, world, port, which, q):
                     for e in lg.edges():
                         if e.output_id == n:
                             lg.connect(e.output_id, e.input_id, e.output_slot, e.input_slot)
+        assert ev.stats["native"] and ev.stats["transport"] == "ipc"
+        kc.sync()
+        kc.comm_destroy()
         q.put((rank, out, ev.stats, len(ev.plan.transfers)))
         dist.barrier()
     finally:

@@ -287,3 +287,42 @@ def test_an_evaluation_of_several_launches_is_replayed(kc, orc, n_branches, sub_
         assert_planes(got, want, what="another source, evaluation %d" % rep)
     kc.set_specialize(1)
     kc.set_option("wide", 1)
+
+
+def test_lazy_embedded_image_forced_from_outside_is_never_replayed_on_freed_operands(kc, orc):
+    """An embedded image may be an unevaluated chain (mix_process result) whose operands only its own links keep alive.  The
+    recorded launches of such an evaluation read those operands; once the image has been forced from outside (an export) the
+    operands go back to the pool and may be recycled.  The recording must not be kept (or must keep the operands itself):
+    every later evaluation equals the oracle."""
+    h, w = 48, 96
+    a, b = synthetic_rgba(SEED_A, h, w), synthetic_rgba(SEED_B, h, w)
+    c = synthetic_rgba(0x5EED0003, h, w)
+    kc.set_option("replay", 1)
+    ia, ib = kc.SlotImage.from_planes(a), kc.SlotImage.from_planes(b)
+    lazy = kc.mix_process(ia, ib, kc.MixType.Add)  # not evaluated yet
+    del ia, ib  # the chain's links are now the only owners of A's and B's planes
+    tp = kc.TextureProcessor.new()
+    lg = tp.new_live_graph()
+    lg.embed_slot_data_with_id(kc.SlotData(0, 0, lazy), 0)
+    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(c)), 1)
+    ne = lg.add_node(kc.Node.new(kc.NodeType.Embed(0)))
+    nc = lg.add_node(kc.Node.new(kc.NodeType.Embed(1)))
+    m1 = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Multiply)))
+    m2 = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Subtract)))
+    lg.connect(ne, m1, 0, 0)
+    lg.connect(nc, m1, 0, 1)
+    lg.connect(m1, m2, 0, 0)
+    lg.connect(nc, m2, 0, 1)
+    s = [orc.mix_plane("Add", a[k], b[k]) for k in range(3)]
+    want = [orc.mix_plane("Subtract", orc.mix_plane("Multiply", s[k], c[k]), c[k]) for k in range(3)] + [np.ones((h, w), np.float32)]
+    for rep in range(4):  # reach the steady state (replaying, if the recording qualified)
+        lg.connect(ne, m1, 0, 0)
+        assert_planes(lg.await_clean(m2).slot_data(m2, 0).image.planes(), want, what="evaluation %d" % rep)
+    # force the embedded image from outside: its chain runs, its links (and with them A and B) are released
+    assert_planes(lazy.planes(), s + [np.ones((h, w), np.float32)], what="the embedded image itself")
+    kc.pool_trim()  # the operand blocks are hipFree'd ...
+    junk = [kc.SlotImage.from_planes([np.full((h, w), np.nan, np.float32)] * 4) for _ in range(4)]  # ... and their addresses recycled
+    for rep in range(3):
+        lg.connect(ne, m1, 0, 0)
+        assert_planes(lg.await_clean(m2).slot_data(m2, 0).image.planes(), want, what="after the outside force, evaluation %d" % rep)
+    del junk

@@ -170,6 +170,25 @@ def check_plan(graph, root, plan, world):
     # execution order: a transfer's producer never depends on a later transfer's data arriving at its rank
     levels = [lv for (_, _, _, _, lv) in plan.transfers]
     assert levels == sorted(levels) and plan.levels == (max(levels) + 1 if levels else 1)
+    # ... and strictly: what a transfer's producer needs from other ranks has arrived in an EARLIER level (csrc/comm.cpp works
+    # through a level's sends before its receives).  Ancestors of the producer that sit on its own rank, transitively:
+    parents = {}
+    for e in graph["edges"]:
+        parents.setdefault(e["input_id"], []).append((e["output_id"], e["output_slot"]))
+    for (n, s, src, dst, lv) in plan.transfers:
+        stack, seen = [n], set()
+        while stack:
+            x = stack.pop()
+            if x in seen:
+                continue
+            seen.add(x)
+            for (p, ps) in parents.get(x, []):
+                pr = nodes[p][0]
+                if pr == -1 or pr == src:
+                    stack.append(p)  # computed (or held) on the producer's rank: look further up
+                else:
+                    inbound = [l2 for (n2, s2, a2, d2, l2) in plan.transfers if (n2, s2, a2, d2) == (p, ps, pr, src)]
+                    assert inbound and inbound[0] < lv, "transfer of node %d at level %d needs node %d, which arrives at level %s" % (n, lv, p, inbound)
     return nodes
 
 
@@ -337,3 +356,58 @@ def test_partitioned_evaluation_over_gloo_equals_single_process(world, which):
     for rank, _, _, _, evaluated in outs:
         for n in evaluated:
             assert n == root or any(t[0] == n and t[2] == rank for t in transfers)
+
+
+# ------------------------------------------------------------------------------------------ one GPU, branches or row bands
+def test_auto_prices_one_gpu_branches_and_row_bands_for_config4():
+    """BASELINE config #4 (eight 16-node branches + add tree): every node is pointwise (src/node/mix.rs:136-192), so a band plan
+    moves only 1/world of the result per rank.  With the default rates (153 GB/s per link, 6.1 TB/s of HBM) that beats one GPU
+    from three ranks on; branches never do (each branch result is a whole image over one link)."""
+    from rank_scenarios import case
+    graph, root, sizes = case("config4", 4096, 4096)
+    lg = host_live_graph(graph)
+    with pytest.raises(kc.TexProError):  # sizes unknown: no band plan can be cut
+        lg.partition(root, 8, kc.PartitionPolicy.Bands)
+    assert lg.partition(root, 8, kc.PartitionPolicy.Auto).kind == kc.PlanKind.Single  # ... and AUTO falls back
+    for eid, (h, w) in sizes.items():  # constant placeholders carry the sizes: all a plan needs
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_value((w, h), 0.0, True)), eid)
+    kinds = {world: lg.partition(root, world, kc.PartitionPolicy.Auto) for world in (1, 2, 3, 4, 8)}
+    assert [kinds[w].kind for w in (1, 2, 3, 4, 8)] == [kc.PlanKind.Single, kc.PlanKind.Single, kc.PlanKind.Bands, kc.PlanKind.Bands, kc.PlanKind.Bands]
+    p8 = kinds[8]
+    assert p8.transfers == [] and p8.full_size == (4096, 4096) and p8.bands == [(512 * r, 512 * (r + 1)) for r in range(8)]
+    assert all(r == -1 for (_, r, _, _) in p8.nodes)
+    assert p8.estimates["bands"] < p8.estimates["single"] < lg.partition(root, 8, kc.PartitionPolicy.Spread).estimates["branches"]
+    # uneven heights: the first `height % world` ranks take one more row
+    graph, root, sizes = case("config4", 37, 16)
+    lg = host_live_graph(graph)
+    for eid, (h, w) in sizes.items():
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_value((w, h), 0.0, True)), eid)
+    assert lg.partition(root, 3, kc.PartitionPolicy.Bands).bands == [(0, 13), (13, 25), (25, 37)]
+    with pytest.raises(kc.TexProError):  # fewer rows than ranks
+        lg.partition(root, 16, kc.PartitionPolicy.Bands) if False else lg.partition(root, 64, kc.PartitionPolicy.Bands)
+    # a slower link makes the bands lose to one GPU again
+    kc.set_option("link_gbps", 20)
+    try:
+        assert lg.partition(root, 3, kc.PartitionPolicy.Auto).kind == kc.PlanKind.Single
+    finally:
+        kc.set_option("link_gbps", 153)
+
+
+def test_linear_chain_is_never_gathered_by_auto():
+    """BASELINE config #3's shape (one fused chain): the result's transfer alone costs more than the chain, so AUTO stays on
+    one GPU; a caller whose consumer is row-parallel too asks for bands and switches the gather off."""
+    g = G()
+    a, b = g.add({"Embed": 0}), g.add({"Embed": 1})
+    prev = a
+    for i in range(8):
+        n = g.add({"Mix": "Add" if i & 1 else "Multiply"})
+        g.connect(prev, n, 0, 0)
+        g.connect(b, n, 0, 1)
+        prev = n
+    lg = host_live_graph(g.dict())
+    for eid in (0, 1):
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_value((8192, 8192), 0.0, True)), eid)
+    assert lg.partition(prev, 8, kc.PartitionPolicy.Auto).kind == kc.PlanKind.Single
+    plan = lg.partition(prev, 2, kc.PartitionPolicy.Bands)
+    plan.set_gather(False)
+    assert plan.kind == kc.PlanKind.Bands and plan.bands == [(0, 4096), (4096, 8192)] and not plan.gather
