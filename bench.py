@@ -11,12 +11,14 @@ A "step" is one full evaluation of the graph (every node over every pixel) on in
 resident in HBM.  Rank 0 prints ONE JSON line.
 
 Default workload:
-    N = 1   chain32: the headline.  One launch per step (the 32 nodes are one fused chain); from the third
-            evaluation on it is the run-time specialised kernel (csrc/specialize.cpp; the warm-up waits for the compile).
+    N = 1   chain32: the headline.  One launch per step (the 32 nodes are one fused chain), the kernel compiled for that
+            program (csrc/specialize.cpp) -- taken from the kernel cache at the first evaluation (the build pre-compiles the
+            BASELINE programs), so the warm-up is exactly --warmup steps.
     N > 1   chain32_rows --size 8192: BASELINE config #3 -- the same 32-node graph on 8192x8192, every rank evaluating its
             row band of the result through the library's band path (kc_live_graph_evaluate_band, csrc/bands.cpp) and
             holding only those rows of the inputs.  A pointwise graph needs no halo and no exchange: "scaling": "strong"
-            (fixed total work), time = max over ranks.
+            (fixed total work), time = max over ranks.  A side leg outside the timed region ("gather_to_rank0") then moves the
+            finished bands to rank 0 through the library's communicator, so that a multi-GPU run also measures a transfer.
 
 Other workloads (parity-tested configs of BASELINE.json, reported in DESIGN.md):
     --workload mix1           config #1: one Mix(Add) node, two 4096^2 f32x4 inputs
@@ -25,9 +27,16 @@ Other workloads (parity-tested configs of BASELINE.json, reported in DESIGN.md):
     --workload chain32_rows --size 8192   config #3 split by row bands over the ranks through the library's band path
                               (kc_live_graph_evaluate_band; strong scaling, no exchange)
     --workload fanin          config #4 (any N, also N = 1): 8 independent 16-node subgraphs + a 7-node Mix(Add) tree as ONE
-                              graph that the library's partitioner (kc_live_graph_partition) spreads over the ranks; branch
-                              results go to the home rank as grouped RCCL send/recv of the planes, the join runs there;
-                              per-rank host compute / exchange times in "per_rank"
+                              graph; the library's partitioner (kc_live_graph_partition, --policy auto | spread | bands)
+                              keeps it on one GPU, places the branches on the ranks (results sent to the home rank) or gives
+                              every rank its row band of the whole graph (finished bands gathered on the home rank); the
+                              library's communicator moves the data; "plan" says which ran, with and without the gather
+    --workload e2e            the host boundary (row f-4): RGBA8 host images in (deconstruct_image) -> the 32-node graph -> RGBA8 out
+                              (to_u8) through the pipelined u8 route (kc_u8_pipe: pinned buffers, copy streams; the upload of image
+                              k + 1 and the download of image k - 1 overlap the evaluation of image k); images/s and the fraction of
+                              the box's measured PCIe rate ("pcie")
+    --cold                    (chain32 / mix1 / resize_blend, N = 1) the timed region itself rotates over 4 instances on different
+                              inputs: the run whose kernel trace reproduces roofline.frac_cold
 Every workload run with N = 1 also carries a "parity" object: the timed graph's result against the oracle.
 """
 import argparse
@@ -66,6 +75,25 @@ def add_chain(kc, lg, src_a, src_b, n_nodes):
     return first, prev
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask and the cgroup CPU quota count, not just what the box has."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def embed(kc, lg, image, eid):
     lg.embed_slot_data_with_id(kc.SlotData(0, 0, image), eid)
     return lg.add_node(kc.Node.new(kc.NodeType.Embed(eid)))
@@ -76,16 +104,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default=None, choices=["chain32", "chain32_rows", "mix1", "resize_blend", "fanin"],
+    ap.add_argument("--workload", default=None, choices=["chain32", "chain32_rows", "mix1", "resize_blend", "fanin", "e2e"],
                     help="default: chain32 at 4096^2 (the headline) on one GPU; on several, chain32_rows at 8192^2 = BASELINE "
                          "config #3, the 32-node graph split by row bands through the library's band path")
-    ap.add_argument("--policy", default="spread", choices=["spread", "auto"], help="fanin: placement policy of the partitioner")
+    ap.add_argument("--policy", default="auto", choices=["spread", "auto", "bands"],
+                    help="fanin: placement policy of the partitioner (auto = the cheapest of one GPU / branches / row bands + gather)")
+    ap.add_argument("--cold", action="store_true",
+                    help="the timed region rotates over 4 instances of the workload on different inputs (nothing of a step is left in "
+                         "the Infinity Cache): what roofline.frac_cold measures, as the main region -- for profiling that case")
     ap.add_argument("--size", type=int, default=None, help="default 4096; 8192 for the multi-GPU default workload")
     ap.add_argument("--nodes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the unfused and PCIe-inclusive side measurements")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (default); gloo only to rehearse the N > 1 control flow on one GPU")
+                    help="torch.distributed backend for the barrier and the reductions of the timing (nccl = RCCL; gloo to rehearse "
+                         "N > 1 with several processes on one GPU); plane data moves through the library's communicator either way")
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "chain32" if args.gpus == 1 else "chain32_rows"
@@ -267,62 +300,129 @@ def main():
         alg_bytes = (3 + 3) * 4.0 * S * S + 3 * 4.0 * s_small * s_small
         kernel = "resize_chain_kernel<2,3>"
         desc = "B %d^2 -> %d^2 Triangle resize + 3-node blend chain, BASELINE config #2" % (s_small, S)
+    elif args.workload == "e2e":
+        assert world == 1, "e2e is a single-GPU workload"
+        depth = 3
+        pipe = kc.U8Pipe(S, S, 4, depth)
+        rng = np.random.default_rng(0x5EED)
+        host_imgs = [rng.integers(0, 256, size=(S, S, 4), dtype=np.uint8) for _ in range(depth)]
+        for sl in range(depth):
+            pipe.in_buffer(sl)[...] = host_imgs[sl]  # a real job decodes its files straight into these pinned buffers
+        host_b = synth(SEED_B, S)
+        img_b = kc.SlotImage.from_planes(host_b)
+        white = kc.SlotImage.from_value((S, S), 1.0, True)
+
+        def graph_on(img):
+            # the 32-node graph of the headline through the per-node operator boundary (mix::process, src/node/mix.rs:51-134)
+            x = img
+            for i in range(1, N + 1):
+                if i & 1:
+                    x = kc.mix_process(x, img_b, kc.MixType.Multiply if (i >> 1) & 1 else kc.MixType.Add)
+                else:
+                    x = kc.mix_process(white, x, kc.MixType.Subtract)
+            return x
+
+        e2e = {"k": 0, "img": pipe.upload(0), "last": None}
+
+        def step():
+            k = e2e["k"]
+            sl = k % depth
+            res = graph_on(e2e["img"])
+            if k >= depth:
+                pipe.wait_download(sl)  # the slot's previous image must have reached the host (and been consumed) first
+            pipe.download(sl, res)      # forces the chain: one fused launch + to_u8, then the copy on the pipe's stream
+            e2e["img"] = pipe.upload((k + 1) % depth)  # next image: its copy runs during the kernels just enqueued
+            e2e["last"] = (sl, k % depth)
+            e2e["k"] = k + 1
+
+        g = None
+        node_px = float(N) * S * S
+        # per image: from_u8 (4 B read, 16 B written per pixel), the fused graph (36 B), to_u8 (12 B read -- alpha is a constant -- 4 B written)
+        alg_bytes = (20.0 + 36.0 + 16.0) * S * S
+        kernel = "from_u8_kernel + kc_chain_<hash> + to_u8_kernel per image"
+        desc = ("RGBA8 host image in -> %d-node graph at %dx%d -> RGBA8 host image out, pipelined u8 route (kc_u8_pipe, depth %d)" % (N, S, S, depth))
     else:  # fanin
         # BASELINE config #4 as ONE graph that every rank builds: 8 independent 16-node subgraphs + a fixed-order 7-node
-        # Mix(Add) tree.  The library's partitioner (csrc/partition.cpp) places the subgraphs on the ranks and the join
-        # region on the home rank; multi_gpu.PartitionedEvaluator moves the cut slots (RCCL send / recv over xGMI, R, G, B
-        # of each branch result; the constant alpha travels as a scalar).  Each rank embeds only the sources placed on it.
+        # Mix(Add) tree.  The library's partitioner (csrc/partition.cpp) decides -- one GPU, branches placed on the ranks with
+        # the join on the home rank, or every rank its row band of the whole graph + a gather of the finished bands -- and the
+        # library's communicator moves what has to move (csrc/comm.cpp).  Each rank holds only the data its plan gives it.
         from kanter_core_amd.multi_gpu import PartitionedEvaluator
         n_branches, sub_nodes = 8, 16
+
+        def build_fanin(lg):
+            srcs, firsts, lasts = [], [], []
+            for k in range(n_branches):
+                na = lg.add_node(kc.Node.new(kc.NodeType.Embed(2 * k)))
+                nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(2 * k + 1)))
+                first, last = add_chain(kc, lg, na, nb, sub_nodes)
+                srcs.append((na, nb))
+                firsts.append(first)
+                lasts.append(last)
+            level = list(lasts)
+            while len(level) > 1:
+                nxt = []
+                for i in range(0, len(level) - 1, 2):
+                    n = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)))
+                    lg.connect(level[i], n, 0, 0)
+                    lg.connect(level[i + 1], n, 0, 1)
+                    nxt.append(n)
+                if len(level) & 1:
+                    nxt.append(level[-1])
+                level = nxt
+            return srcs, firsts, lasts, level[0]
+
+        policy = {"spread": kc.PartitionPolicy.Spread, "auto": kc.PartitionPolicy.Auto, "bands": kc.PartitionPolicy.Bands}[args.policy]
+        # the plan, from a probe graph whose sources are constant placeholders of the right size (no HBM behind them)
+        probe = tp.new_live_graph()
+        build_fanin(probe)
+        for e in range(2 * n_branches):
+            probe.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_value((S, S), 0.0, True)), e)
         lg = tp.new_live_graph()
-        srcs, firsts, lasts = [], [], []
-        for k in range(n_branches):
-            na = lg.add_node(kc.Node.new(kc.NodeType.Embed(2 * k)))
-            nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(2 * k + 1)))
-            first, last = add_chain(kc, lg, na, nb, sub_nodes)
-            srcs.append((na, nb))
-            firsts.append(first)
-            lasts.append(last)
-        level = list(lasts)
-        while len(level) > 1:
-            nxt = []
-            for i in range(0, len(level) - 1, 2):
-                n = lg.add_node(kc.Node.new(kc.NodeType.Mix(kc.MixType.Add)))
-                lg.connect(level[i], n, 0, 0)
-                lg.connect(level[i + 1], n, 0, 1)
-                nxt.append(n)
-            if len(level) & 1:
-                nxt.append(level[-1])
-            level = nxt
-        root = level[0]
-        header_group = dist.new_group(backend="gloo") if (world > 1 and args.dist_backend == "nccl") else None
-        ev = PartitionedEvaluator(lg, root, policy=kc.PartitionPolicy.Spread if args.policy == "spread" else kc.PartitionPolicy.Auto,
-                                  device=torch.device("cuda", device_index), header_group=header_group)
-        placed = {n: r for (n, r, _, _) in ev.plan.nodes}
-        mine = [k for k in range(n_branches) if placed[lasts[k]] == rank]
-        for k in range(n_branches):
-            for j, (node, seed) in enumerate(zip(srcs[k], (0x5EED0100 + k, 0x5EED0200 + k))):
-                if placed[node] == rank:
-                    planes = [splitmix_plane(seed, c, S, S) for c in range(4)]
-                    lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(planes)), 2 * k + j)
+        srcs, firsts, lasts, root = build_fanin(lg)
+        probe_plan = probe.partition(root, world, policy)
+        seeds = lambda k: (0x5EED0100 + k, 0x5EED0200 + k)  # noqa: E731
+        if probe_plan.kind == kc.PlanKind.Bands:
+            fy0, fy1 = probe_plan.bands[rank]
+            need = probe.band_source_rows(root, fy0, fy1)
+            for k in range(n_branches):
+                for j, (node, seed) in enumerate(zip(srcs[k], seeds(k))):
+                    a_, b_, _, fh = need[node]
+                    planes = [splitmix_rows(seed, c, S, S, a_, b_) for c in range(4)]  # pointwise graph: no wrapped rows
+                    lg.embed_slot_data_band(kc.SlotData(0, 0, kc.SlotImage.from_planes(planes)), 2 * k + j, a_, fh)
+            mine = list(range(n_branches))
+            my_rows = fy1 - fy0
+        else:
+            placed = {n: r for (n, r, _, _) in probe_plan.nodes}
+            mine = [k for k in range(n_branches) if placed[lasts[k]] == rank]
+            for k in range(n_branches):
+                for j, (node, seed) in enumerate(zip(srcs[k], seeds(k))):
+                    if placed[node] == rank:
+                        planes = [splitmix_plane(seed, c, S, S) for c in range(4)]
+                        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(planes)), 2 * k + j)
+            my_rows = S
+        del probe
+        ev = PartitionedEvaluator(lg, root, policy=policy)
+        assert ev.plan.kind == probe_plan.kind and ev.plan.transfers == probe_plan.transfers and ev.plan.bands == probe_plan.bands
         g = (lg, None, None, root)
         keep = []
 
         def step():
-            for k in mine:
-                lg.connect(srcs[k][0], firsts[k], 0, 0)  # re-plugging the input dirties the branch and what joins it
+            if ev.plan.kind != kc.PlanKind.Bands:
+                for k in mine:
+                    lg.connect(srcs[k][0], firsts[k], 0, 0)  # re-plugging the input dirties the branch and what joins it
             keep[:] = [ev.evaluate()]
 
         n_tree = n_branches - 1
-        node_px = float(len(mine) * sub_nodes + (n_tree if rank == ev.plan.home else 0)) * S * S
-        # per rank: its fused subgraphs (36 B/px each); home: the add tree over 8 resident RGB results -- 4 launches reading
-        # 2, 2, 3, 4 planes and writing 1 each, per channel.  An upper bound only: what the launches really move is decided
-        # at run time (on one rank, pairs of branches and their Mix(Add) share a program: 5 launches, 25 plane passes per
-        # channel) and is what the library counts -- the roofline below uses that count (algorithmic_bytes_per_step).
-        alg_bytes = len(mine) * 36.0 * S * S + ((15 * 3 * 4.0 * S * S) if rank == ev.plan.home else 0.0)
-        kernel = "chain_kernel<2,*> per subgraph + RCCL send/recv + chain_kernel<2..4,*> add tree"
-        desc = ("8 independent 16-node subgraphs at %dx%d f32x4 placed by kc_live_graph_partition (%s), branch results sent to "
-                "the home rank over RCCL, 7-node Mix(Add) tree there, BASELINE config #4" % (S, S, args.policy))
+        if ev.plan.kind == kc.PlanKind.Bands:
+            node_px = float(n_branches * sub_nodes + n_tree) * S * my_rows
+        else:
+            node_px = float(len(mine) * sub_nodes + (n_tree if rank == ev.plan.home else 0)) * S * S
+        # an upper bound only: what the launches really move is decided at run time and is what the library counts -- the
+        # roofline below uses that count (algorithmic_bytes_per_step)
+        alg_bytes = len(mine) * 36.0 * S * my_rows + ((15 * 3 * 4.0 * S * my_rows) if rank == ev.plan.home else 0.0)
+        kernel = "kc_chain_<hash> (config #4's programs compiled to straight-line code, csrc/specialize.cpp)"
+        desc = ("8 independent 16-node subgraphs + 7-node Mix(Add) tree at %dx%d f32x4, BASELINE config #4; plan of kc_live_graph_partition "
+                "(policy %s): %s" % (S, S, args.policy, ("one GPU", "branches, results sent to the home rank", "row bands + gather on the home rank")[ev.plan.kind]))
 
     def barrier():
         torch.cuda.synchronize()
@@ -345,31 +445,52 @@ def main():
     host_us = []  # host time of every step of the last timed() call
     extra_warmup = [0]  # untimed steps run in addition to --warmup after a kernel compile landed (see warm())
 
+    first_sightings = {}  # what the steps before a compile landed took (only when this process had to compile)
+
     def warm(stepfn, warmup):
-        # The first sightings of a chain program run through the interpreter while the program-specialised kernel
-        # compiles on a worker thread (csrc/specialize.cpp); the rest of the warm-up starts once it has landed.
-        # A graph's first evaluation builds plain chains and the programs that join chains / read more than four planes are
-        # first seen at the second one (csrc/graph.cpp await_clean), so compiles are queued in up to three waves: pairs of
-        # steps, each followed by a wait, until a pair queues nothing new.
-        early = 0
-        c0 = kc.specialize_stats()["kernels_compiled"]
-        for _ in range(4):
-            if early + 2 > warmup:
-                break
-            c1 = kc.specialize_stats()["kernels_compiled"]
+        # Compiled kernels outlive the process (csrc/specialize.cpp, kernel cache: the build pre-compiles the BASELINE programs,
+        # every other program is written to ~/.cache/kanter_core_amd by the process that first compiles it), so normally the first
+        # evaluation already runs the kernel of its program and the warm-up is EXACTLY the `warmup` steps asked for.
+        # Only when this process has to compile (a fresh cache): the first sightings run through the interpreter while hiprtc
+        # works on a worker thread (~2 s for the first program, GPU idle, clocks down), so the steps wait for the compile and a
+        # few more untimed steps bring the clocks back -- counted and reported (extra_warmup_after_kernel_compile), along with
+        # what the interpreter steps took.
+        c0 = kc.specialize_stats()
+        done = 0
+        for _ in range(min(2, warmup)):
+            stepfn()
+            done += 1
+        c1 = kc.specialize_stats()
+        compiling = world == 1 and (c1["kernels_compiled"] > c0["kernels_compiled"] or c1["compiles_pending"] > 0)
+        if world > 1:  # every rank must run the same number of steps: the ranks agree on whether anybody compiles
+            flag = torch.tensor([float(c1["kernels_compiled"] > c0["kernels_compiled"] or c1["compiles_pending"] > 0)], device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            compiling = flag.item() > 0
+        extra = 0
+        if compiling:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
             stepfn()
             stepfn()
-            early += 2
-            kc.specialize_wait()
-            # (with several ranks every rank runs the same number of steps: a step of the fan-in workload exchanges planes)
-            if world == 1 and early > 2 and kc.specialize_stats()["kernels_compiled"] == c1:
-                break
-        # The GPU sat idle while hiprtc ran (~2 s for the first program of a process) and its clocks went down with it:
-        # when a compile did land, a few more untimed steps bring them back before the timed region (which stays EXACTLY
-        # `steps` steps; the JSON reports the requested warm-up count and these extra ones separately).
-        extra = 40 if (world > 1 or kc.specialize_stats()["kernels_compiled"] > c0) else 0
+            e1.record(stream)
+            torch.cuda.synchronize()
+            first_sightings["ms_per_step"] = round(e0.elapsed_time(e1) / 2, 4)
+            first_sightings["note"] = "steps of this run before its kernel had been compiled (interpreter / cut chains)"
+            extra += 2
+            for _ in range(3):  # programs that join chains are first built at the evaluation after the one that queued them
+                kc.specialize_wait()
+                before = kc.specialize_stats()["kernels_compiled"]
+                stepfn()
+                stepfn()
+                extra += 2
+                kc.specialize_wait()
+                if kc.specialize_stats()["kernels_compiled"] == before:
+                    break
+            for _ in range(40):
+                stepfn()
+            extra += 40
         extra_warmup[0] += extra
-        for _ in range(max(warmup - early, 1 if early else 0) + extra):
+        for _ in range(warmup - done):
             stepfn()
 
     def timed(stepfn, steps, warmup, sync_ranks=True):
@@ -417,7 +538,42 @@ def main():
         torch.cuda.synchronize()
         return sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(steps))
 
-    wall, dev_s, launches = timed(step, args.steps, args.warmup)
+    def measure_pcie(mb=64, reps=16):
+        """The box's PCIe rates with pinned memory: H2D alone, D2H alone, both at once (GB/s per direction)."""
+        n = mb << 20
+        hin, hout = torch.empty(n, dtype=torch.uint8, pin_memory=True), torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        din, dout = torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda")
+        s_up, s_dn = torch.cuda.Stream(), torch.cuda.Stream()
+
+        def run(up, down):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                if up:
+                    with torch.cuda.stream(s_up):
+                        din.copy_(hin, non_blocking=True)
+                if down:
+                    with torch.cuda.stream(s_dn):
+                        hout.copy_(dout, non_blocking=True)
+            torch.cuda.synchronize()
+            return n * reps / (time.perf_counter() - t0) / 1e9
+
+        run(True, True)
+        return {"h2d_GBps": round(run(True, False), 1), "d2h_GBps": round(run(False, True), 1),
+                "duplex_GBps_per_direction": round(run(True, True), 1), "how": "%d MB pinned copies (the size of one RGBA8 4096^2 image), %d in a row per direction" % (mb, reps)}
+
+    main_step = step
+    if args.cold:
+        assert world == 1 and band is None and args.workload in ("chain32", "mix1", "resize_blend"), "--cold: single-GPU chain32 / mix1 / resize_blend"
+        rot = [step] + [make_cold(i) for i in range(3)]
+        rot_i = [0]
+
+        def main_step():
+            rot[rot_i[0] % len(rot)]()
+            rot_i[0] += 1
+        args.steps = max(len(rot), args.steps // len(rot) * len(rot))
+        args.warmup = max(2 * len(rot), args.warmup // len(rot) * len(rot))
+    wall, dev_s, launches = timed(main_step, args.steps, args.warmup)
     extra_main = extra_warmup[0]
     main_host_us = list(host_us)
     # Algorithmic bytes: the per-kernel figures of DESIGN.md section 3 summed by the library over the launches of a step
@@ -432,7 +588,7 @@ def main():
                   "first sightings only)") if kc.specialize_stats()["specialized_launches"] else "upsample_chain_kernel<2,3,true>"
     elif kc.specialize_stats()["specialized_launches"] and "chain_kernel<" in kernel:
         kernel = "kc_chain_<hash> (the chain program compiled to straight-line code at run time, csrc/specialize.cpp; " + kernel + " = the interpreter, first sightings only)"
-    main_step_us = step_spread(step, max(20, min(args.steps, 100)))
+    main_step_us = step_spread(main_step, max(20, min(args.steps, 100)))
     total_px = node_px
     job_bytes, job_dev_s = alg_bytes, dev_s
     if world > 1:
@@ -475,6 +631,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "extra_warmup_after_kernel_compile": extra_main,
+        "kernel_cache": kc.kernel_cache_stats(),
         "ms_per_step": round(wall / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "strong" if (args.workload == "fanin" or band_note) else "weak",
@@ -487,14 +644,23 @@ def main():
             "series": ("%s at %dx%d: the line for --gpus N of this workload and size; N = 1 runs the same graph through the same path"
                        % ("chain32_rows (one graph split by row bands, strong scaling)" if band is not None else args.workload, S, S)),
             "cache_policy": kc.get_cache_policy(),
+            "timed_region": ("4 instances of the workload on different inputs in rotation (--cold): nothing a step touches is left in the Infinity Cache"
+                             if args.cold else "one graph re-evaluated on the same resident inputs (the contract's step)"),
+            "frac_includes_infinity_cache_hits": bool(kc.get_cache_policy()) and not args.cold,
             "parallelism": (("row bands of one graph through kc_live_graph_evaluate_band, no exchange" if band is not None else
                              "independent graph per GPU") if args.workload != "fanin"
-                            else "branches placed by the library's partitioner + RCCL send/recv to the home rank")
+                            else "plan of the library's partitioner (see \"plan\"), data moved by the library's communicator")
             if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": peak_gbs, "unit": "GB/s",
-            "frac": round(achieved / peak_gbs, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "frac": round(achieved / peak_gbs, 4), "frac_cold": round(achieved / peak_gbs, 4) if args.cold else None,
+            "frac_definition": ("algorithmic bytes of a step / HIP-event time of a step / (n_gpus x 8 TB/s).  frac: the timed region as the contract "
+                                "defines it -- ONE graph re-evaluated on the same resident inputs; with cache_policy = 1 one long-lived input "
+                                "(192 MB) can stay in the 256 MB Infinity Cache from step to step, so frac is a fabric-side figure that can exceed "
+                                "what HBM alone delivers (6.3 TB/s measured copy = 0.79).  frac_cold: the same steps rotated over 4 instances on "
+                                "different inputs -- everything comes from HBM -- the HBM-only fraction"),
+            "traffic": traffic, "traffic_source": traffic_source,
             "scope": "whole job: all ranks' algorithmic bytes / slowest rank's time / (n_gpus x 8 TB/s)" if world > 1 else "one GPU",
             "algorithmic_bytes_per_launch": alg_bytes / max(launches_per_step, 1.0) if launches_per_step else alg_bytes,
             "algorithmic_bytes_per_step": alg_bytes, "closed_form_bytes_per_step": formula_bytes,
@@ -508,7 +674,43 @@ def main():
         },
     }
 
-    if rank == 0 and world == 1 and band is None and args.workload in ("chain32", "mix1", "resize_blend") and not args.no_extras:
+    if first_sightings:
+        out["first_sightings"] = dict(first_sightings)
+    if args.workload == "e2e":
+        for sl in range(depth):
+            pipe.wait_download(sl)
+        pcie = measure_pcie()
+        per_image_s = wall / args.steps
+        in_b, out_b = 4.0 * S * S, 4.0 * S * S
+        bound_s = max(in_b, out_b) / (pcie["duplex_GBps_per_direction"] * 1e9)  # both directions at once, each at its duplex rate
+        out["metric"] = "images/s, RGBA8 %dx%d in -> %d-node graph -> RGBA8 out (host to host)" % (S, S, N)
+        out["value"] = round(1.0 / per_image_s, 1)
+        out["unit"] = "images/s"
+        out["roofline"] = {"bound": "pcie", "achieved": round(in_b / per_image_s / 1e9, 2), "peak": pcie["duplex_GBps_per_direction"],
+                           "unit": "GB/s", "frac": round(bound_s / per_image_s, 4),
+                           "frac_definition": "time the slower direction of one image needs at the measured full-duplex PCIe rate / measured time per image",
+                           "gpu_side": {"algorithmic_bytes_per_image": alg_bytes, "hbm_time_us_at_6.1TBps": round(alg_bytes / 6.1e12 * 1e6, 1)},
+                           "launches_per_step": launches_per_step, "traffic": None}
+        out["pcie"] = pcie
+        out["bytes_per_image"] = {"in": in_b, "out": out_b, "f32_route_would_move": 2 * 16.0 * S * S}
+        if not args.no_cpu_baseline:
+            # parity: what reached the host for the last image of every slot against the oracle's deconstruct -> graph -> to_u8 on
+            # three 32-row crops (the graph is pointwise)
+            from oracle import oracle as orc
+            orc.set_threads(usable_cores())
+            mism = checked = 0
+            for sl in range(depth):
+                got = pipe.out_buffer(sl)
+                for r0 in (0, S // 2 - 16, S - 32):
+                    a_pl = orc.deconstruct_u8(host_imgs[sl][r0:r0 + 32])
+                    ref = orc.chain32(a_pl, [p[r0:r0 + 32] for p in host_b], N)
+                    want_u8 = orc.to_u8(orc.Image(ref))
+                    mism += int((got[r0:r0 + 32] != want_u8).sum())
+                    checked += 32 * S * 4
+            orc.set_threads(1)
+            out["parity"] = {"checked_bytes": checked, "byte_mismatches": mism}
+        pipe.close()
+    if rank == 0 and world == 1 and band is None and args.workload in ("chain32", "mix1", "resize_blend") and not args.no_extras and not args.cold:
         # ---- cold: nothing a step touches can still be in the 256 MB Infinity Cache ----
         # The timed region above re-evaluates ONE graph on the same inputs (what an editor does, and what the contract asks
         # for); with the cache policy (csrc/runtime.cpp, chain_cache_policy) one long-lived input of it stays in the Infinity
@@ -523,15 +725,13 @@ def main():
 
         kc_steps = max(20, min(args.steps, 100)) // len(cold_steps) * len(cold_steps)
         wall_c, dev_c, launches_c = timed(cold_step, kc_steps, 2 * len(cold_steps), sync_ranks=False)
+        out["roofline"]["frac_cold"] = round(counted[0] * kc_steps / dev_c / 1e9 / HBM_PEAK_GBS, 4)
         out["roofline"]["cold"] = {
             "kernel_us": round(dev_c / max(launches_c, 1) * 1e6, 2), "frac": round(counted[0] * kc_steps / dev_c / 1e9 / HBM_PEAK_GBS, 4),
             "steps": kc_steps,
             "how": "4 instances of the workload on different inputs evaluated in rotation: inputs and results of a step were last "
                    "touched more than 1.5 GB of traffic earlier, so the 256 MB Infinity Cache holds none of them",
         }
-        out["roofline"]["warm_note"] = ("frac is the contract's measurement: one graph re-evaluated on resident inputs; with "
-                                        "cache_policy = 1 a long-lived input can stay in the Infinity Cache between steps, which is how "
-                                        "frac can exceed what HBM alone delivers (~0.80); cold.frac excludes that")
         del cold_steps
 
     if rank == 0 and args.workload == "chain32" and not args.no_extras and band is None:
@@ -555,8 +755,12 @@ def main():
         _, lastp = add_chain(kc, lgp, pa, pb, N)
         res = lgp.await_clean(lastp).slot_data(lastp, 0).image.planes()
         pcie_s = time.perf_counter() - t0
+        moved = (8 + 4) * 4.0 * S * rows
         out["pcie_inclusive"] = {"value": round(node_px / pcie_s / 1e6, 1), "unit": "Mpix/s", "seconds": round(pcie_s, 4),
-                                 "note": "8 pageable host planes uploaded, 4 downloaded, graph built and evaluated once"}
+                                 "bytes_moved": moved, "GBps": round(moved / pcie_s / 1e9, 1),
+                                 "note": "the f32 route, blocking: 8 pageable host planes uploaded, 4 downloaded, graph built and evaluated "
+                                         "once (12 x 64 MB over PCIe, one direction at a time).  The u8 route moves a quarter of that and "
+                                         "overlaps the directions: --workload e2e gives its rate and its fraction of the box's PCIe peak"}
         del res, lgp
 
     if rank == 0 and world == 1 and args.workload == "chain32" and not args.no_cpu_baseline and band is None:
@@ -574,30 +778,51 @@ def main():
                       "sequentially, as the reference's one-thread-per-node engine runs a linear chain" % (reps, N, S, S, cpu_s),
             "host_cores_available": os.cpu_count(),
         }
-        # the same loops, rows split over the host cores of this GPU's share of the box (SURVEY 8(d) ii)
-        threads = max(1, min(os.cpu_count() or 1, 16))
-        if threads > 1:
+        # the same loops, rows split over host cores (SURVEY 8(d) ii): every core of the box, and one GPU's share of them (1/8)
+        def cpu_many(threads, pool):
             orc.set_threads(threads)
-            orc.chain32(host_a, host_b, N)  # first touch / thread start-up
+            orc.set_plane_pool(pool)
             t0 = time.perf_counter()
-            for _ in range(3):
+            orc.chain32(host_a, host_b, N)  # thread start-up, first touch
+            first = time.perf_counter() - t0
+            t0, n = time.perf_counter(), 0
+            while n < 1 or (n < 3 and first < 4.0) or (time.perf_counter() - t0 < 3.0 and n < 12 and first < 1.0):
                 orc.chain32(host_a, host_b, N)
-            mt_s = time.perf_counter() - t0
+                n += 1
+            dt = time.perf_counter() - t0
             orc.set_threads(1)
-            out["cpu_baseline_all_cores"] = {"value": round(float(N) * S * S * 3 / mt_s / 1e6, 2), "unit": "Mpix/s",
-                                             "cores": threads, "kind": "port",
-                                             "note": "a reported baseline, not a target: %d of the box's %d cores (one GPU's share); the port keeps the "
-                                                     "reference's per-node plane allocation and first touch, which do not parallelise" % (threads, os.cpu_count() or 1),
-                                             "sample": "3 evaluations, rows split over %d OpenMP threads = one GPU's share of the box's %d host cores (%.1f s)" % (threads, os.cpu_count() or 1, mt_s)}
+            orc.set_plane_pool(False)
+            return round(float(N) * S * S * n / dt / 1e6, 2), n, dt
+
+        box_cores, all_cores = os.cpu_count() or 1, usable_cores()
+        if all_cores > 1:
+            v, n, dt = cpu_many(all_cores, True)
+            if all_cores > 16 and v < 2.0 * out["cpu_baseline"]["value"]:
+                # more threads than the machine lets this process run at once (a CPU share enforced where neither the affinity
+                # mask nor cpu.max shows it): the run with one GPU's share of the cores is the honest "all I can use" figure
+                out["cpu_baseline_oversubscribed"] = {"value": v, "cores": all_cores, "sample": "%d evaluations (%.1f s)" % (n, dt)}
+                all_cores = 16
+                v, n, dt = cpu_many(all_cores, True)
+            out["cpu_baseline_all_cores"] = {
+                "value": v, "unit": "Mpix/s", "cores": all_cores, "kind": "port", "host_cores_in_the_box": box_cores,
+                "note": "a reported baseline, not a target.  Rows split over every host core this process may use (affinity mask and "
+                        "cgroup CPU quota: %d of the box's %d); planes released by a node are reused by the next one "
+                        "(oracle.set_plane_pool) -- with the reference's allocate-per-node the page faults of the fresh 64 MiB mappings "
+                        "serialise in the kernel and the run does not scale (cpu_baseline_per_node_alloc keeps that form)" % (all_cores, box_cores),
+                "sample": "%d evaluations (%.1f s)" % (n, dt)}
+            v, n, dt = cpu_many(all_cores, False)
+            out["cpu_baseline_per_node_alloc"] = {
+                "value": v, "unit": "Mpix/s", "cores": all_cores, "kind": "port",
+                "note": "the same threads with the reference's per-node plane allocation kept", "sample": "%d evaluations (%.1f s)" % (n, dt)}
         # parity of the timed workload against the oracle, on the same inputs
         got = g[0].slot_data(g[3], 0).image.planes()
         mism = int(sum((x.view(np.uint32) != y.view(np.uint32)).sum() for x, y in zip(got, ref)))
         out["parity"] = {"checked_pixels": S * rows * 4, "bit_mismatches": mism}
 
-    if rank == 0 and world == 1 and args.workload in ("mix1", "resize_blend", "fanin") and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and args.workload in ("mix1", "resize_blend", "fanin") and not args.no_cpu_baseline and g is not None:
         # parity of the timed graph against the oracle on the same inputs (the oracle as checker, after the timed region)
         from oracle import oracle as orc
-        orc.set_threads(max(1, min(os.cpu_count() or 1, 16)))
+        orc.set_threads(usable_cores())
         if args.workload == "mix1":
             ref = [orc.mix_plane("Add", host_a[c], host_b[c]) for c in range(3)]
         elif args.workload == "resize_blend":
@@ -671,11 +896,60 @@ def main():
         st["branches"] = len(mine)
         if world > 1:
             allst = [None] * world
-            dist.all_gather_object(allst, st, group=header_group)
+            dist.all_gather_object(allst, st)
         else:
             allst = [st]
         out["per_rank"] = [{k: (round(v, 6) if isinstance(v, float) else v) for k, v in x.items()} for x in allst]
+        out["plan"] = {"kind": ("single", "branches", "bands")[ev.plan.kind], "policy": args.policy,
+                       "estimates_in_units_of_one_fused_rgba_chain": ev.plan.estimates, "bands": ev.plan.bands or None,
+                       "transfers": len(ev.plan.transfers), "transport": kc.comm_transport() or None}
+        if ev.plan.kind == kc.PlanKind.Bands and world > 1:
+            # the same plan with the bands left where they are (a consumer that is row-parallel too): what the gather costs
+            ev.plan.set_gather(False)
+            wall_ng, dev_ng, _ = timed(step, max(5, args.steps // 2), 2)
+            ev.plan.set_gather(True)
+            t = torch.tensor([wall_ng], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out["plan"]["ms_per_step_without_gather"] = round(float(t[0].item()) / max(5, args.steps // 2) * 1e3, 4)
         out["multi_gpu_measured"] = world > 1 and args.dist_backend == "nccl"
+
+    if band is not None and world > 1:
+        # The default N > 1 workload moves no plane (a pointwise graph by rows needs no exchange).  This leg does: every rank's
+        # finished band goes to rank 0's row offset through the library's communicator (kc_comm_gather_bands), so that a multi-GPU
+        # run also carries a measured transfer.  Outside the timed region above; never part of `value`.
+        leg = {}
+        try:
+            from kanter_core_amd.multi_gpu import ensure_communicator
+            ensure_communicator(rank, world)
+            lgb, _, _, lastb = g
+            k_g = max(3, min(args.steps, 20))
+
+            def gather_step():
+                b_img = lgb.evaluate_band(lastb, band[0], band[1])
+                band_keep[:] = [kc.comm_gather_bands(b_img, band[0], S, 0)]
+
+            wall_g, dev_g, _ = timed(gather_step, k_g, 2)
+            t = torch.tensor([wall_g], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            moved = 3.0 * 4 * S * (S - (multi_gpu.row_bands(S, world)[0][1] - multi_gpu.row_bands(S, world)[0][0]))
+            leg = {"ms_per_step": round(float(t[0].item()) / k_g * 1e3, 4), "steps": k_g, "transport": kc.comm_transport(),
+                   "bytes_into_rank0_per_step": moved, "inbound_GBps": round(moved / (float(t[0].item()) / k_g) / 1e9, 1),
+                   "what": "band evaluation + gather of the R, G, B rows of the other ranks' bands into rank 0's image (alpha is a constant)"}
+            if rank == 0 and not args.no_cpu_baseline:
+                from oracle import oracle as orc
+                got = band_keep[0].planes()
+                mism = 0
+                for r0 in (0, S // 2 - 16, S - 32):  # crops in the first, a middle and the last band
+                    ha = [splitmix_rows(SEED_A, c, S, S, r0, r0 + 32) for c in range(4)]
+                    hb = [splitmix_rows(SEED_B, c, S, S, r0, r0 + 32) for c in range(4)]
+                    ref = orc.chain32(ha, hb, N)
+                    mism += int(sum((got[c][r0:r0 + 32].view(np.uint32) != np.ascontiguousarray(ref[c]).view(np.uint32)).sum() for c in range(4)))
+                leg["parity"] = {"checked_pixels": 3 * 32 * S * 4, "bit_mismatches": mism}
+            band_keep[:] = []
+        except Exception as e:  # noqa: BLE001 -- the headline line must survive a failing side leg
+            leg = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["gather_to_rank0"] = leg
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

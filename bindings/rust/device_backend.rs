@@ -16,7 +16,7 @@
 use crate::kanter_core_amd_sys::*;
 use crate::{edge::Edge, error::{Result, TexProError}, node::{mix::MixType, Node, ResizeFilter, ResizePolicy},
             node_graph::SlotId, slot_data::{Size, SlotData}};
-use std::{ffi::CStr, ptr, sync::Arc};
+use std::{ffi::CStr, os::raw::c_void, ptr, sync::Arc};
 
 /// Owned reference to a device image (kc_image is reference counted by the library).
 pub struct DeviceImage(ptr::NonNull<KcImage>);
@@ -183,24 +183,73 @@ pub(crate) fn resize_buffers(slot_datas: &[Arc<SlotData>], edges: &[Edge], polic
 }
 
 // ------------------------------------------------------------------------------------------------
-// Several GPUs (one process per GPU; round 2).  The reference has no such layer; these are the two
-// calls a Rust host adds around `LiveGraph` (see INTEGRATION.md section 6 for the exchange loop).
+// Several GPUs (one process per GPU).  The reference has no such layer; these are the calls a Rust host adds
+// around `LiveGraph`: join the communicator once, make a plan, evaluate it.  The library moves the data itself
+// (csrc/comm.cpp); INTEGRATION.md section 6 shows the whole sequence.
 // ------------------------------------------------------------------------------------------------
 
-/// Which rank evaluates which ancestor of `root`, and which slots cross a rank boundary -- the same
-/// answer on every rank, derived from the graph alone (kc_live_graph_partition, csrc/partition.cpp).
-pub fn partition(lg: *mut KcLiveGraph, root: NodeId, world: i32, spread: bool) -> Result<(Vec<KcPlacement>, Vec<KcTransfer>)> {
-    let mut plan = ptr::null_mut();
-    check(unsafe { kc_live_graph_partition(lg, root.0, world, if spread { 1 } else { 0 }, &mut plan) })?;
-    let (mut n, mut t) = (0u32, 0u32);
-    check(unsafe { kc_partition_nodes(plan, ptr::null_mut(), 0, &mut n) })?;
-    check(unsafe { kc_partition_transfers(plan, ptr::null_mut(), 0, &mut t) })?;
-    let mut nodes = vec![KcPlacement { node_id: 0, rank: 0, component: 0, kind: 0 }; n as usize];
-    let mut xfers = vec![KcTransfer { node_id: 0, slot_id: 0, src_rank: 0, dst_rank: 0, level: 0 }; t as usize];
-    check(unsafe { kc_partition_nodes(plan, nodes.as_mut_ptr(), n, &mut n) })?;
-    check(unsafe { kc_partition_transfers(plan, xfers.as_mut_ptr(), t, &mut t) })?;
-    unsafe { kc_partition_free(plan) };
-    Ok((nodes, xfers))
+/// How the evaluation of one node is spread over the ranks (kc_live_graph_partition, csrc/partition.cpp): the same answer
+/// on every rank, derived from the graph alone.  Owns the library's plan.
+pub struct Plan {
+    raw: *mut KcPartition,
+    /// 0 = one GPU, 1 = branches (`transfers` cross rank boundaries), 2 = row bands (`bands`)
+    pub kind: i32,
+    pub nodes: Vec<KcPlacement>,
+    pub transfers: Vec<KcTransfer>,
+    /// rows [y0, y1) of the requested node per rank (band plans)
+    pub bands: Vec<KcBandRange>,
+}
+
+impl Drop for Plan {
+    fn drop(&mut self) { unsafe { kc_partition_free(self.raw); } }
+}
+
+/// rank 0: the identifier every rank passes to `comm_init` (hand it over by any channel the host has)
+pub fn comm_unique_id() -> Result<[u8; 256]> {
+    let mut id = [0u8; 256];
+    check(unsafe { kc_comm_unique_id(id.as_mut_ptr() as *mut c_void) })?;
+    Ok(id)
+}
+
+/// collective over all ranks of the node, after `kc_init`
+pub fn comm_init(rank: i32, world: i32, id: &[u8; 256]) -> Result<()> {
+    check(unsafe { kc_comm_init(rank, world, id.as_ptr() as *const c_void) })
+}
+
+pub fn comm_destroy() -> Result<()> { check(unsafe { kc_comm_destroy() }) }
+
+/// policy: 0 = the cheapest of {one GPU, branches, row bands + gather}, 1 = branches, 2 = row bands
+pub fn partition(lg: *mut KcLiveGraph, root: NodeId, world: i32, policy: i32) -> Result<Plan> {
+    let mut raw = ptr::null_mut();
+    check(unsafe { kc_live_graph_partition(lg, root.0, world, policy, &mut raw) })?;
+    let mut plan = Plan { raw, kind: 0, nodes: Vec::new(), transfers: Vec::new(), bands: Vec::new() };
+    check(unsafe { kc_partition_kind(raw, &mut plan.kind, ptr::null_mut(), ptr::null_mut(), ptr::null_mut()) })?;
+    let (mut n, mut t, mut b) = (0u32, 0u32, 0u32);
+    check(unsafe { kc_partition_nodes(raw, ptr::null_mut(), 0, &mut n) })?;
+    check(unsafe { kc_partition_transfers(raw, ptr::null_mut(), 0, &mut t) })?;
+    check(unsafe { kc_partition_bands(raw, ptr::null_mut(), 0, &mut b, ptr::null_mut(), ptr::null_mut()) })?;
+    plan.nodes = vec![KcPlacement { node_id: 0, rank: 0, component: 0, kind: 0 }; n as usize];
+    plan.transfers = vec![KcTransfer { node_id: 0, slot_id: 0, src_rank: 0, dst_rank: 0, level: 0 }; t as usize];
+    plan.bands = vec![KcBandRange { y0: 0, y1: 0 }; b as usize];
+    check(unsafe { kc_partition_nodes(raw, plan.nodes.as_mut_ptr(), n, &mut n) })?;
+    check(unsafe { kc_partition_transfers(raw, plan.transfers.as_mut_ptr(), t, &mut t) })?;
+    check(unsafe { kc_partition_bands(raw, plan.bands.as_mut_ptr(), b, &mut b, ptr::null_mut(), ptr::null_mut()) })?;
+    Ok(plan)
+}
+
+/// The whole evaluation of a plan (kc_live_graph_evaluate_partitioned): the exchange of a branch plan and the root on the
+/// home rank, or this rank's rows of a band plan and the gather.  `Some(image)` on the home rank, `None` elsewhere.
+pub fn evaluate_partitioned(lg: *mut KcLiveGraph, plan: &Plan, root: NodeId) -> Result<Option<SlotImage>> {
+    let mut out = ptr::null_mut();
+    check(unsafe { kc_live_graph_evaluate_partitioned(lg, plan.raw, root.0, &mut out) })?;
+    Ok(if out.is_null() { None } else { Some(wrap(out)) })
+}
+
+/// Every rank passes its band; the assembled image on `home` (kc_comm_gather_bands).
+pub fn gather_bands(band: &SlotImage, y0: i32, full_height: u32, home: i32) -> Result<Option<SlotImage>> {
+    let mut out = ptr::null_mut();
+    check(unsafe { kc_comm_gather_bands(band.raw(), y0, full_height, home, &mut out) })?;
+    Ok(if out.is_null() { None } else { Some(wrap(out)) })
 }
 
 /// Rows [y0, y1) of `node`'s slot, bit-identical to those rows of the whole-image evaluation

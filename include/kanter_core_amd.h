@@ -87,6 +87,7 @@ typedef struct kc_node_graph kc_node_graph;
 typedef struct kc_live_graph kc_live_graph;
 typedef struct kc_tex_pro kc_tex_pro;
 typedef struct kc_partition kc_partition;   /* multi-GPU placement plan of one graph evaluation */
+typedef struct kc_u8_pipe kc_u8_pipe;       /* pipelined u8 host boundary (pinned buffers, copy streams) */
 
 /* Size, src/slot_data.rs:4-30 */
 typedef struct kc_size { uint32_t width, height; } kc_size;
@@ -151,7 +152,9 @@ KC_API int kc_get_cache_policy(void);
  *   interpreter's 4 while such a kernel is not there); 0: 4, as before.  Bit-identical either way.
  *   "down2" 0 / 1 (default) / 2: down-sampling with more than 8 taps on both axes runs resize_down2_kernel never / except
  *   where the integer-ratio streaming kernel runs at ratio 4 or 8 / wherever its tables exist (bit-identical; A/B and tests).
- *   "link_gbps" (153), "hbm_gbps" (6100): the rates kc_live_graph_partition prices a transfer / a streaming kernel with. */
+ *   "link_gbps" (153), "hbm_gbps" (6100): the rates kc_live_graph_partition prices a transfer / a streaming kernel with.
+ *   "cache_budget_mb" (208, env KC_CACHE_BUDGET_MB): how much of a launch's streams the cache policy leaves cacheable -- 13/16 of
+ *   the MI355X's 256 MB Infinity Cache; HIP reports no size for that cache, so another part sets this. */
 KC_API int kc_set_option(const char *name, int value);
 KC_API int kc_get_option(const char *name, int *value);
 /* Diagnostics (host only, works without a device): the structure the integer-ratio up-sampling kernels rely on,
@@ -207,6 +210,23 @@ KC_API int kc_specialize_compile_check(const uint32_t *words, uint32_t n_ops, ui
  * src/node/mix.rs:136-192 in one launch. */
 KC_API int kc_specialize_compile_check_upsample(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, uint32_t taps,
                                                 int wide, char *source, size_t cap);
+/* Compiled kernels outlive the process: every code object hiprtc produces is written to a directory, and the FIRST sighting of a
+ * program in a later process loads it from there (no compile, no interpreter run) -- the reference's own usage is one evaluation
+ * per process (tests/integration_tests.rs:47-49).  Directory: KC_KERNEL_CACHE_DIR, default $XDG_CACHE_HOME/kanter_core_amd or
+ * ~/.cache/kanter_core_amd ("off": none); read-only second place: kernel_cache/ next to the library, filled by the build with
+ * the BASELINE programs.  A file is trusted only if its signature equals the program's byte for byte, the hash of what TODAY's
+ * generator, options and hiprtc version produce for it equals the stored one and the code's checksum holds; anything else is
+ * ignored and replaced by a fresh compile.
+ *   kc_kernel_cache_set_dir   NULL / "": the environment's choice again; "off": no cache;
+ *   kc_kernel_cache_stats     files accepted / refused / written, kernels this process took from files;
+ *   kc_kernel_cache_precompile  compiles the program given by value (step words as for kc_specialize_compile_check, cache-policy
+ *                             mask, up_taps > 0: the up-sampling form) WITHOUT a device and writes its file into `dir`;
+ *   kc_specialize_reset       forgets the kernels this process holds (files stay): the next sighting is a first one. */
+KC_API int kc_kernel_cache_set_dir(const char *dir);
+KC_API int kc_kernel_cache_stats(uint64_t *files_accepted, uint64_t *files_refused, uint64_t *files_written, uint64_t *kernels_loaded);
+KC_API int kc_kernel_cache_precompile(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, int flat, uint32_t nt_mask,
+                                      uint32_t up_taps, int up_wide, const char *dir);
+KC_API int kc_specialize_reset(void);
 
 /* ========================================================================================== *
  * Planes -- replaces Buffer / TransientBufferContainer (src/slot_image.rs:12,
@@ -247,6 +267,23 @@ KC_API int kc_image_materialize(kc_image *img);
 KC_API int kc_image_from_u8(const uint8_t *host, uint32_t width, uint32_t height, int channels, kc_image **out);
 /* to_u8 / to_u8_srgb, src/slot_image.rs:141-207: -> interleaved RGBA8 (width*height*4 bytes). */
 KC_API int kc_image_to_u8(kc_image *img, int srgb, uint8_t *host_rgba8);
+/* The same two as a PIPELINE for jobs that run one graph over many images: `depth` slots, each with a pinned host buffer for an
+ * input image (width * height * channels bytes), one for an RGBA8 output image, and device staging for both; the copies run on
+ * two streams of the pipe's own, ordered with the compute stream by events, so the upload of image k + 1 and the download of
+ * image k - 1 overlap the evaluation of image k and no call waits on the host except kc_u8_pipe_wait_download.
+ *   kc_u8_pipe_buffers        the slot's buffers: fill `*host_in` before kc_u8_pipe_upload, read `*host_out` after
+ *                             kc_u8_pipe_wait_download (and before the slot's next kc_u8_pipe_download);
+ *   kc_u8_pipe_upload         deconstruct_image of the slot's input buffer: `*out` (+1 ref) is usable at once (its planes are
+ *                             ready in stream order).  Call it for the NEXT image after the current one's evaluation has been
+ *                             enqueued -- the copy then runs during that evaluation;
+ *   kc_u8_pipe_download       to_u8 (srgb = 0) / to_u8_srgb (1) of `img` into the slot's output buffer, asynchronously;
+ *   kc_u8_pipe_wait_download  blocks until that buffer holds the image. */
+KC_API int kc_u8_pipe_create(uint32_t width, uint32_t height, int channels, int depth, kc_u8_pipe **out);
+KC_API int kc_u8_pipe_free(kc_u8_pipe *pipe);
+KC_API int kc_u8_pipe_buffers(kc_u8_pipe *pipe, int slot, uint8_t **host_in, const uint8_t **host_out);
+KC_API int kc_u8_pipe_upload(kc_u8_pipe *pipe, int slot, kc_image **out);
+KC_API int kc_u8_pipe_download(kc_u8_pipe *pipe, int slot, kc_image *img, int srgb);
+KC_API int kc_u8_pipe_wait_download(kc_u8_pipe *pipe, int slot);
 KC_API int kc_image_from_f32(const float *const host_planes[], int n_planes, uint32_t width, uint32_t height, kc_image **out);
 KC_API int kc_image_to_f32(kc_image *img, float *const host_planes[], int n_planes);
 /* read_slot_image, src/shared.rs:218-261 (PNG only; decode on host, planes built on device). */

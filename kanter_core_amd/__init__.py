@@ -11,6 +11,7 @@ from .api import (Edge, EmbeddedSlotDataId, LiveGraph, MixType, Node, NodeGraph,
                   shutdown, stats, sync, value_process, set_specialize, get_specialize, specialize_wait,
                   specialize_stats, specialize_compile_check, Partition, PartitionPolicy, NodeKind, set_resize_mode,
                   get_resize_mode, resize_upsample_plan, resize_down2_plan, stats_counter, specialize_compile_check_upsample, set_cache_policy, get_cache_policy, set_option, get_option, comm_unique_id, comm_init,
-                  comm_destroy, comm_info, comm_stats, comm_transport, comm_gather_bands, PlanKind, pool_trim)
+                  comm_destroy, comm_info, comm_stats, comm_transport, comm_gather_bands, PlanKind, pool_trim, kernel_cache_set_dir, kernel_cache_stats,
+                  kernel_cache_precompile, specialize_reset, U8Pipe)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

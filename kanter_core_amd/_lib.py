@@ -68,6 +68,16 @@ SIGNATURES = {
     "kc_comm_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "kc_live_graph_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "kc_comm_transport": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "kc_u8_pipe_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "kc_u8_pipe_free": (C.c_int, [C.c_void_p]),
+    "kc_u8_pipe_buffers": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "kc_u8_pipe_upload": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "kc_u8_pipe_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "kc_u8_pipe_wait_download": (C.c_int, [C.c_void_p, C.c_int]),
+    "kc_kernel_cache_set_dir": (C.c_int, [C.c_char_p]),
+    "kc_kernel_cache_stats": (C.c_int, [C.POINTER(C.c_uint64)] * 4),
+    "kc_kernel_cache_precompile": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p]),
+    "kc_specialize_reset": (C.c_int, []),
     "kc_comm_gather_bands": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
     "kc_live_graph_evaluate_partitioned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "kc_set_option": (C.c_int, [C.c_char_p, C.c_int]),

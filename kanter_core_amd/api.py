@@ -254,6 +254,29 @@ def stats():
     return {"bytes_in_use": a.value, "bytes_cached": b.value, "kernel_launches": c.value, "algorithmic_bytes": d.value}
 
 
+def kernel_cache_set_dir(path):
+    """Where compiled kernels are kept between processes (csrc/specialize.cpp); None: the environment's choice, "off": nowhere."""
+    _check(_lib.load().kc_kernel_cache_set_dir(None if path is None else str(path).encode()))
+
+
+def kernel_cache_stats():
+    v = [C.c_uint64() for _ in range(4)]
+    _check(_lib.load().kc_kernel_cache_stats(*[C.byref(x) for x in v]))
+    return dict(zip(("files_accepted", "files_refused", "files_written", "kernels_loaded"), (x.value for x in v)))
+
+
+def kernel_cache_precompile(words, n_in, start_src, flat, nt_mask, directory, up_taps=0, up_wide=False):
+    """Compiles the program given by its step words with hiprtc (no device needed) and writes its code object into `directory`."""
+    arr = (C.c_uint32 * len(words))(*words)
+    _check(_lib.load().kc_kernel_cache_precompile(arr, len(words), int(n_in), int(start_src), int(bool(flat)), int(nt_mask),
+                                                  int(up_taps), int(bool(up_wide)), str(directory).encode()))
+
+
+def specialize_reset():
+    """Forgets every kernel this process has compiled or loaded: the next sighting of a program is a first one."""
+    _check(_lib.load().kc_specialize_reset())
+
+
 def pool_trim():
     """kc_pool_trim: waits for the stream and gives every cached (free) block back to the driver."""
     _check(_lib.load().kc_pool_trim())
@@ -1020,6 +1043,60 @@ class LiveGraph:
     def add_input_slot_data(self, slot_data):
         _check(_lib.load().kc_live_graph_add_input_slot_data(self._h, slot_data.node_id, slot_data.slot_id,
                                                              slot_data.image._h))
+
+
+class U8Pipe:
+    """The u8 host boundary as a pipeline (csrc/u8pipe.cpp; include/kanter_core_amd.h kc_u8_pipe_*): `depth` slots of pinned
+    buffers, uploads and downloads on copy streams of their own, overlapping the evaluations between them.
+
+        pipe = U8Pipe(w, h, depth=3)
+        pipe.in_buffer(s)[...] = pixels           # (h, w, channels) uint8 view of pinned memory
+        img = pipe.upload(s)                      # SlotImage, usable at once
+        pipe.download(s, result, srgb=False)      # asynchronous
+        out = pipe.wait_download(s)               # (h, w, 4) uint8 view, valid until the slot's next download"""
+
+    def __init__(self, width, height, channels=4, depth=3):
+        h = C.c_void_p()
+        _check(_lib.load().kc_u8_pipe_create(int(width), int(height), int(channels), int(depth), C.byref(h)))
+        self._h, self.width, self.height, self.channels, self.depth = h, int(width), int(height), int(channels), int(depth)
+
+    def close(self):
+        if self._h:
+            _check(_lib.load().kc_u8_pipe_free(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _buffers(self, slot):
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(_lib.load().kc_u8_pipe_buffers(self._h, int(slot), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def in_buffer(self, slot):
+        p, _ = self._buffers(slot)
+        n = self.width * self.height * self.channels
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(p)).reshape(self.height, self.width, self.channels)
+
+    def out_buffer(self, slot):
+        _, p = self._buffers(slot)
+        n = self.width * self.height * 4
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(p)).reshape(self.height, self.width, 4)
+
+    def upload(self, slot):
+        out = C.c_void_p()
+        _check(_lib.load().kc_u8_pipe_upload(self._h, int(slot), C.byref(out)))
+        return SlotImage(out.value)
+
+    def download(self, slot, image, srgb=False):
+        _check(_lib.load().kc_u8_pipe_download(self._h, int(slot), image._h, int(bool(srgb))))
+
+    def wait_download(self, slot):
+        _check(_lib.load().kc_u8_pipe_wait_download(self._h, int(slot)))
+        return self.out_buffer(slot)
 
 
 class PartitionPolicy:

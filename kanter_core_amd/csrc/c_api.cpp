@@ -78,6 +78,7 @@ try {
     }
     if (const char *rm = std::getenv("KC_RESIZE_MODE")) c.resize_mode = std::atoi(rm);
     if (const char *cp = std::getenv("KC_CACHE_POLICY")) c.cache_policy = std::atoi(cp) != 0;
+    if (const char *cb = std::getenv("KC_CACHE_BUDGET_MB")) c.cache_budget_mb = std::max(0, std::atoi(cb));
     if (const char *c1 = std::getenv("KC_CHAIN1")) c.chain1 = std::atoi(c1) != 0;
     if (const char *j = std::getenv("KC_JOIN")) c.join = std::atoi(j) != 0;
     if (const char *wd = std::getenv("KC_WIDE")) c.wide = std::atoi(wd) != 0;
@@ -238,6 +239,7 @@ try {
     else if (std::strcmp(name, "join") == 0) ctx().join = value != 0;
     else if (std::strcmp(name, "wide") == 0) ctx().wide = value != 0;
     else if (std::strcmp(name, "down2") == 0 && value >= 0 && value <= 2) ctx().down2 = value;
+    else if (std::strcmp(name, "cache_budget_mb") == 0 && value >= 0) ctx().cache_budget_mb = value;
     else if (std::strcmp(name, "link_gbps") == 0 && value > 0) ctx().link_gbps = value;
     else if (std::strcmp(name, "hbm_gbps") == 0 && value > 0) ctx().hbm_gbps = value;
     else {
@@ -256,6 +258,7 @@ try {
     else if (std::strcmp(name, "join") == 0) *value = ctx().join ? 1 : 0;
     else if (std::strcmp(name, "wide") == 0) *value = ctx().wide ? 1 : 0;
     else if (std::strcmp(name, "down2") == 0) *value = ctx().down2;
+    else if (std::strcmp(name, "cache_budget_mb") == 0) *value = ctx().cache_budget_mb;
     else if (std::strcmp(name, "link_gbps") == 0) *value = ctx().link_gbps;
     else if (std::strcmp(name, "hbm_gbps") == 0) *value = ctx().hbm_gbps;
     else {
@@ -359,6 +362,43 @@ try {
     int s = specialize_compile_only(P, &log);
     if (s != KC_OK) set_error("specialised chain kernel did not compile: " + log);
     return s;
+}
+KC_CATCH
+
+int kc_kernel_cache_set_dir(const char *dir)
+try {
+    Lock lk(ctx().mu);
+    return kernel_cache_set_dir(dir);
+}
+KC_CATCH
+
+int kc_kernel_cache_stats(uint64_t *hits, uint64_t *rejected, uint64_t *written, uint64_t *kernels_loaded)
+try {
+    kernel_cache_stats(hits, rejected, written, kernels_loaded);
+    return KC_OK;
+}
+KC_CATCH
+
+int kc_kernel_cache_precompile(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int start_src, int flat, uint32_t nt_mask,
+                               uint32_t up_taps, int up_wide, const char *dir)
+try {
+    KC_ARG(words && dir);
+    std::string log;
+    const int s = kernel_cache_precompile(words, n_ops, n_in, start_src, flat != 0, nt_mask, up_taps, up_wide != 0, dir, &log);
+    if (s != KC_OK) set_error("kernel cache: " + log);
+    return s;
+}
+KC_CATCH
+
+// Forgets every kernel this process has compiled or loaded (the files stay): the next sighting of a program is a first one.
+int kc_specialize_reset(void)
+try {
+    Lock lk(ctx().mu);
+    if (ctx().stream) (void)hipStreamSynchronize(ctx().stream);
+    const int mode = specialize_get_mode();
+    specialize_shutdown();
+    (void)mode;
+    return KC_OK;
 }
 KC_CATCH
 
@@ -1351,6 +1391,55 @@ try {
     image_retain(image);
     lg->input_slot_datas.push_back(SlotData{ node_id, slot_id, image });
     return KC_OK;
+}
+KC_CATCH
+
+// ---------------------------------------------------------------- the u8 boundary as a pipeline (u8pipe.cpp)
+int kc_u8_pipe_create(uint32_t width, uint32_t height, int channels, int depth, kc_u8_pipe **out)
+try {
+    Lock lk(ctx().mu);
+    KC_ARG(out);
+    return u8_pipe_create(width, height, channels, depth, out);
+}
+KC_CATCH
+
+int kc_u8_pipe_free(kc_u8_pipe *pipe)
+try {
+    Lock lk(ctx().mu);
+    return u8_pipe_free(pipe);
+}
+KC_CATCH
+
+int kc_u8_pipe_buffers(kc_u8_pipe *pipe, int slot, uint8_t **host_in, const uint8_t **host_out)
+try {
+    Lock lk(ctx().mu);
+    KC_ARG(pipe);
+    return u8_pipe_buffers(pipe, slot, host_in, host_out);
+}
+KC_CATCH
+
+int kc_u8_pipe_upload(kc_u8_pipe *pipe, int slot, kc_image **out)
+try {
+    Lock lk(ctx().mu);
+    KC_ARG(pipe && out);
+    return u8_pipe_upload(pipe, slot, out);
+}
+KC_CATCH
+
+int kc_u8_pipe_download(kc_u8_pipe *pipe, int slot, kc_image *img, int srgb)
+try {
+    Lock lk(ctx().mu);
+    KC_ARG(pipe && img);
+    return u8_pipe_download(pipe, slot, img, srgb != 0);
+}
+KC_CATCH
+
+int kc_u8_pipe_wait_download(kc_u8_pipe *pipe, int slot)
+try {
+    KC_ARG(pipe);
+    kc_u8_pipe *p = pipe;
+    (void)p;
+    return u8_pipe_wait_download(pipe, slot);  // no context lock: only this call blocks, and only on the slot's own event
 }
 KC_CATCH
 

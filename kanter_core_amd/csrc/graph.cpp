@@ -1056,13 +1056,15 @@ int kc_live_graph::await_clean(uint32_t id)
     bool replayed = false;
     KC_TRY(replay_try(*this, id, &replayed));
     if (replayed) return KC_OK;
-    // A graph's FIRST evaluation builds its chains the way every kernel can run them (4 input planes, no joined chains): a
-    // process that evaluates a graph once must not pay for programs whose own kernels it will never see compiled.  From the
-    // second evaluation on the chains are built for those kernels (csrc/runtime.cpp chain_in_limit / join_ok); "compile at
-    // first sight" (kc_set_specialize(2)) has them from the start.
+    // A graph's FIRST evaluation builds its chains the way every kernel can run them (4 input planes, no joined chains) when
+    // there is no chance of finding a compiled kernel for anything else: a process that evaluates a graph once must not pay for
+    // programs whose own kernels it will never see compiled.  From the second evaluation on the chains are built for those
+    // kernels (csrc/runtime.cpp chain_in_limit / join_ok); "compile at first sight" (kc_set_specialize(2)) has them from the
+    // start, and so has a process that finds code objects of earlier processes or of the build on disk (specialize.cpp,
+    // kernel cache) -- where a program's kernel is missing all the same, chain_launch cuts the chain as before.
     Context &c = ctx();
     const bool plain_before = c.plain_chains;
-    c.plain_chains = plain_before || (walks == 0 && specialize_get_mode() == 1);
+    c.plain_chains = plain_before || (walks == 0 && specialize_get_mode() == 1 && !kernel_cache_populated());
     ReplayRecorder *rec = replay_begin(*this, id);
     const int s = await_clean_walk(id);
     c.plain_chains = plain_before;

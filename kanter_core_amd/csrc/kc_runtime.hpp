@@ -230,6 +230,7 @@ struct Context {
     bool chain1 = true;  // one-step programs run the ahead-of-time kernels of chain1.hip (kc_set_option("chain1", 0): interpreter / specialiser, A/B and tests)
     int link_gbps = 153;   // one xGMI link, what the planner charges a transfer with (kc_set_option("link_gbps"))
     int hbm_gbps = 6100;   // what a streaming kernel gets from HBM with nothing in the Infinity Cache (kc_set_option("hbm_gbps"))
+    int cache_budget_mb = 208;  // what a launch may leave cacheable: 13/16 of the 256 MB Infinity Cache of an MI355X, the share that measured best (profiles/r03_tilecopy4.txt); kc_set_option("cache_budget_mb") / KC_CACHE_BUDGET_MB for another part
     int cache_policy = 1;  // 1: launches whose streams exceed the Infinity Cache mark them nontemporal (cache_policy_mask); 0: plain loads / stores (KC_CACHE_POLICY, kc_set_cache_policy)
     int max_blocks = 4096;
     int chain_unroll = 0;  // float4 per thread per decode in the chain kernel; 0 = heuristic (KC_CHAIN_UNROLL)
@@ -373,6 +374,20 @@ std::string specialize_last_log();
 void specialize_shutdown();
 std::string specialize_source(const ChainProgram &P, const UpsampleArgs *U = nullptr);
 int specialize_compile_only(const ChainProgram &P, std::string *log, const UpsampleArgs *U = nullptr);
+// code objects that outlive the process (specialize.cpp, "code objects that outlive the process")
+int kernel_cache_set_dir(const char *dir);
+void kernel_cache_stats(uint64_t *hits, uint64_t *rejected, uint64_t *written, uint64_t *kernels_loaded);
+bool kernel_cache_populated();
+int kernel_cache_precompile(const uint32_t *words, uint32_t n_ops, uint32_t n_in, int32_t start_src, bool flat, uint32_t nt_mask,
+                            uint32_t up_taps, bool up_wide, const char *dir, std::string *log);
+
+// ---- the u8 boundary as a pipeline (u8pipe.cpp) ----
+int u8_pipe_create(uint32_t w, uint32_t h, int channels, int depth, kc_u8_pipe **out);
+int u8_pipe_free(kc_u8_pipe *p);
+int u8_pipe_buffers(kc_u8_pipe *p, int slot, uint8_t **host_in, const uint8_t **host_out);
+int u8_pipe_upload(kc_u8_pipe *p, int slot, kc_image **out);
+int u8_pipe_download(kc_u8_pipe *p, int slot, kc_image *img, bool srgb);
+int u8_pipe_wait_download(kc_u8_pipe *p, int slot);
 
 // ---- png / json (png.cpp, json.cpp) ----
 int png_read(const std::string &path, std::vector<uint8_t> &px, uint32_t &w, uint32_t &h, int &channels);

@@ -564,7 +564,7 @@ uint32_t chain_cache_policy(const uint32_t *refs, uint32_t n, uint64_t stream_by
     uint32_t all = 0;
     for (uint32_t k = 0; k < n; ++k) all |= KC_CHAIN_NT_BIT(k);
     if (forced >= 0) return (uint32_t)forced & (all | 0x100u);
-    const uint64_t budget = 208ull << 20;
+    const uint64_t budget = (uint64_t)ctx().cache_budget_mb << 20;
     if (n * stream_bytes + out_bytes <= budget) return 0;
     uint32_t mask = all;
     uint64_t used = 0;
@@ -585,7 +585,7 @@ uint32_t cache_policy_mask(uint64_t in_bytes, uint64_t out_bytes, uint32_t n_res
     if (!ctx().cache_policy) return 0;
     static const long forced = std::getenv("KC_NT_FORCE") ? std::strtol(std::getenv("KC_NT_FORCE"), nullptr, 0) : -1;  // tuning: this mask for every launch
     if (forced >= 0) return (uint32_t)forced & (((1u << n_resident) - 1u) | 0x100u);
-    const uint64_t budget = 208ull << 20;
+    const uint64_t budget = (uint64_t)ctx().cache_budget_mb << 20;
     if (in_bytes + out_bytes <= budget) return 0;
     uint32_t mask = (1u << n_resident) - 1u;
     if (out_bytes > budget) mask |= 0x100u;

@@ -488,16 +488,50 @@ KCO_API void kco_to_u8_gray(const float *v, size_t n, int srgb, uint8_t *out)
  * (src/shared.rs:152-207, clamp(v) broadcast) before Mix(Subtract) reads it.
  * a/b: 3 planes each (R,G,B; Mix ignores input alpha), n pixels per plane.  out: 4 planes.
  * ------------------------------------------------------------------------------------------- */
+/* Plane allocation of kco_chain32.  0 (default): every node output is a new allocation that is freed when the node after it has
+ * run, as the reference does (fresh pages from the kernel for each 64 MiB plane, first touched inside the node's loop).
+ * 1: planes released by a node are kept on a list and handed to the next node that needs one -- what a many-core run needs to
+ * scale at all (the page faults of fresh mappings serialise in the kernel); the arithmetic is the same. */
+static int g_plane_pool = 0;
+KCO_API int kco_set_plane_pool(int on)
+{
+    g_plane_pool = on != 0;
+    return g_plane_pool;
+}
+
+#define KCO_POOL_MAX 16
+typedef struct {
+    float *free_list[KCO_POOL_MAX];
+    int n_free;
+    size_t n;
+} kco_pool;
+
+static float *pool_get(kco_pool *p)
+{
+    if (g_plane_pool && p->n_free > 0) return p->free_list[--p->n_free];
+    return (float *)malloc(sizeof(float) * p->n);
+}
+
+static void pool_put(kco_pool *p, float *q)
+{
+    if (!q) return;
+    if (g_plane_pool && p->n_free < KCO_POOL_MAX) p->free_list[p->n_free++] = q;
+    else free(q);
+}
+
 KCO_API int kco_chain32(const float *const a[3], const float *const b[3], float *const out[4], uint32_t w,
                         uint32_t h, int n_nodes)
 {
     size_t n = (size_t)w * h;
+    kco_pool pool;
+    pool.n_free = 0;
+    pool.n = n;
     float *cur[4] = { 0, 0, 0, 0 };
     const float *x[3] = { a[0], a[1], a[2] };
     for (int i = 1; i <= n_nodes; i++) {
         float *nxt[4];
         for (int c = 0; c < 4; c++) {
-            nxt[c] = (float *)malloc(sizeof(float) * n);
+            nxt[c] = pool_get(&pool);
             if (!nxt[c]) return -1;
         }
         if (i & 1) {
@@ -508,23 +542,24 @@ KCO_API int kco_chain32(const float *const a[3], const float *const b[3], float 
             float one = 1.0f;
             float *white[4];
             for (int c = 0; c < 4; c++) {
-                white[c] = (float *)malloc(sizeof(float) * n);
+                white[c] = pool_get(&pool);
                 if (!white[c]) return -1;
                 kco_resize_plane(&one, 1, 1, white[c], w, h, KCO_TRIANGLE);
             }
             for (int c = 0; c < 3; c++) kco_mix_plane(KCO_SUBTRACT, white[c], x[c], nxt[c], n);
-            for (int c = 0; c < 4; c++) free(white[c]);
+            for (int c = 0; c < 4; c++) pool_put(&pool, white[c]);
         }
         kco_fill(nxt[3], n, 1.0f);
-        for (int c = 0; c < 4; c++) free(cur[c]);
+        for (int c = 0; c < 4; c++) pool_put(&pool, cur[c]);
         for (int c = 0; c < 4; c++) cur[c] = nxt[c];
         for (int c = 0; c < 3; c++) x[c] = cur[c];
     }
     for (int c = 0; c < 4; c++) {
         if (cur[c]) {
             memcpy(out[c], cur[c], sizeof(float) * n);
-            free(cur[c]);
+            pool_put(&pool, cur[c]);
         }
     }
+    while (pool.n_free > 0) free(pool.free_list[--pool.n_free]);
     return 0;
 }

@@ -65,6 +65,8 @@ def lib():
         L.kco_to_u8_gray.restype = None
         L.kco_chain32.argtypes = [C.POINTER(fp), C.POINTER(fp), C.POINTER(fp), C.c_uint32, C.c_uint32, C.c_int]
         L.kco_chain32.restype = C.c_int
+        L.kco_set_plane_pool.argtypes = [C.c_int]
+        L.kco_set_plane_pool.restype = C.c_int
         _lib = L
     return _lib
 
@@ -81,6 +83,12 @@ def _plane(a):
 
 def set_threads(n):
     return lib().kco_set_threads(int(n))
+
+
+def set_plane_pool(on):
+    """chain32 only: planes released by a node are reused by the next (1) instead of freed and allocated afresh as the
+    reference does (0, the default).  Same arithmetic; what lets the many-core run scale."""
+    return lib().kco_set_plane_pool(int(bool(on)))
 
 
 def max_threads():

@@ -5,6 +5,8 @@ set -u
 R=$GRAFT_REPO_ROOT
 W=$1; shift
 cp $R/kanter_core_amd/libkanter_core_amd.so /tmp/base.so
+# whatever ends this script -- the last line, a timeout, Ctrl-C -- the shipped library goes back in place
+trap 'cp /tmp/base.so $R/kanter_core_amd/libkanter_core_amd.so' EXIT
 P='import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); r=d["roofline"]
 print("%-12s kernel_us=%.2f frac=%.3f median=%.2f min=%.2f parity=%s" % (sys.argv[1], r["kernel_us"], r["frac"], r["step_us_median"], r["step_us_min"], d.get("parity")))'

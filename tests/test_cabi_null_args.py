@@ -12,7 +12,9 @@ POINTERISH = (C.c_void_p, C.c_char_p)
 NULL_OK = {"kc_plane_release", "kc_image_release", "kc_node_graph_free", "kc_tex_pro_free", "kc_live_graph_free", "kc_partition_free",
            "kc_specialize_stats",  # every output is optional
            "kc_set_stream", "kc_stats", "kc_comm_info", "kc_comm_stats",  # kc_stats, kc_comm_info / _stats: every output is optional
-           "kc_resize_buffers"}  # n == 0: nothing to resize (src/shared.rs:147-149)
+           "kc_resize_buffers",  # n == 0: nothing to resize (src/shared.rs:147-149)
+           "kc_kernel_cache_set_dir", "kc_kernel_cache_stats",  # NULL directory = the environment's choice; every output is optional
+           "kc_u8_pipe_free"}  # freeing nothing
 
 
 def _is_pointer(t):
