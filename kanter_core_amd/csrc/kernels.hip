@@ -1186,8 +1186,22 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     // of their neighbours' windows, taller ones leave too few waves to overlap one wave's arithmetic with another's loads
     // (bands sized for one wave per SIMD, 20+ rows, were slower still); with four planes per launch the waves are there and
     // 12 / 24 / 36 / 48 rows give 80.5 / 71.2 / 74.8 / 85.4 us.
+    // A launch whose waves are all resident at once lasts as long as ONE wave lives -- A - 1 + rows trips of ~470 vector
+    // instructions each (SQ counters: 13 us of issue + 10 us of waits per wave at ratio 8, profiles/r04_poly_weights.md) -- so
+    // images that do not fill the chip take SHORT bands: 2048^2 -> 512^2 19.3 / 15.3 / 11.5 us with 12 / 8 / 4 rows,
+    // 2048^2 -> 256^2 26.6 / 20.3 / 16.5, 1024^2 -> 256^2 16.7 / 13.2 / 9.6 (profiles/r04_poly_rows_small.txt); past about one
+    // wave per SIMD the windows short bands re-read cost more than their trips save (4096^2 -> 1024^2: 22.2 / 24.7 / 33.5 us).
     static const uint32_t rows_env = std::getenv("KC_POLY_ROWS") ? std::max(4u, (uint32_t)std::atoi(std::getenv("KC_POLY_ROWS")) / 4u * 4u) : 0u;
-    b.rows = rows_env ? rows_env : (batch >= 2 && ages >= 4) ? 24u : 12u;
+    b.rows = (batch >= 2 && ages >= 4) ? 24u : 12u;
+    {
+        const uint64_t strips = (dw + tile_w - 1) / tile_w, regular = (reg_b - reg_a) / 4u * 4u;
+        for (uint32_t r : { 4u, 8u })
+            if (strips * ((regular + r - 1) / r) * (uint64_t)batch <= 1100u) {
+                b.rows = r;
+                break;
+            }
+    }
+    if (rows_env) b.rows = rows_env;
     b.n_bands = (b.yb - b.ya + b.rows - 1) / b.rows;
     b.nyb = (b.n_bands + 3u) / 4u;
     // what is left: rows above the first band and below the last one, as general tiles of at most 16 rows

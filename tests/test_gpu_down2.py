@@ -110,3 +110,24 @@ def test_down2_full_size_non_integer_ratio(kc, orc):
     assert kc.stats_counter("down2_launches") - n0 == (1 if kc.get_option("down2") else 0)
     want = orc.resize_plane(p, 3000, 3000, "Lanczos3")
     assert bit_equal(got, want), max_ulp(got, want)
+
+
+INTEGER_RATIO_CASES = [
+    # integer ratios on the vertical axis (2, 4, 8) with every window length (Triangle 2 ages, CatmullRom 4, Gaussian / Lanczos3 6):
+    # resize_poly_kernel's bands of 4, 8 and 12 rows (it picks the height by how many waves the image gives), widths that leave
+    # partial strips, heights whose regular rows do not fill whole bands
+    ("Lanczos3", (1000, 96), (250, 24)), ("Gaussian", (1024, 512), (128, 64)), ("Triangle", (2048, 256), (256, 32)),
+    ("CatmullRom", (1200, 400), (300, 100)), ("Lanczos3", (516, 1032), (258, 516)), ("Gaussian", (4096, 160), (512, 20)),
+    ("CatmullRom", (640, 1920), (320, 240)), ("Triangle", (808, 1616), (101, 202)), ("Lanczos3", (2000, 2000), (500, 500)),
+    ("Gaussian", (2048, 2048), (256, 256)), ("Lanczos3", (4096, 4096), (1024, 1024)),
+]
+
+
+@pytest.mark.parametrize("kind", ["finite", "nonfinite"])
+@pytest.mark.parametrize("filt,src,dst", INTEGER_RATIO_CASES)
+def test_integer_ratio_down_sampling_equals_oracle(kc, orc, filt, src, dst, kind):
+    (sw, sh), (dw, dh) = src, dst
+    p = source(sh, sw, kind)
+    want = orc.resize_plane(p, dw, dh, filt)
+    got = resize(kc, p, (dw, dh), filt)
+    assert bit_equal(got, want), "%s %s->%s %s max ulp %s" % (filt, src, dst, kind, max_ulp(got, want))

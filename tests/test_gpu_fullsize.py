@@ -181,3 +181,56 @@ def test_resize_down_full_size_vs_oracle(kc, orc, filt, src, dst):
     assert bit_equal(got, want), "%s %s->%s" % (filt, src, dst)
     # the non-finite samples reach exactly the outputs whose windows contain them
     assert np.isnan(got).sum() == np.isnan(want).sum() > 0
+
+
+@pytest.mark.parametrize("size", [4096, 8192])
+def test_compiled_chain_kernels_at_full_size_vs_oracle_crops(kc, orc, size):
+    """The kernels compiled at run time (csrc/specialize.cpp, "compile at first sight") at BASELINE's full sizes: their index
+    arithmetic runs over 16.7 M / 67 M float4 units here, where the small-size tests of tests/test_gpu_specialize.py cannot see
+    it.  The 32-node graph through the LiveGraph (one launch of a kc_chain_* kernel), the first and the last rows and columns and
+    a band in the middle against the oracle on crops; then config #4's 16-plane program at 4096^2 the same way."""
+    from bench import add_chain
+    S = size
+    a = [splitmix_plane(SEED_A, c, S, S) for c in range(4)]
+    b = [splitmix_plane(SEED_B, c, S, S) for c in range(4)]
+    mode = kc.get_specialize()
+    kc.set_specialize(2)
+    try:
+        s0 = kc.specialize_stats()
+        tp = kc.TextureProcessor.new()
+        lg = tp.new_live_graph()
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(a)), 0)
+        lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(b)), 1)
+        na, nb = lg.add_node(kc.Node.new(kc.NodeType.Embed(0))), lg.add_node(kc.Node.new(kc.NodeType.Embed(1)))
+        _, last = add_chain(kc, lg, na, nb, 32)
+        got = lg.await_clean(last).slot_data(last, 0).image.planes()
+        s1 = kc.specialize_stats()
+        assert s1["specialized_launches"] == s0["specialized_launches"] + 1, "the evaluation did not run a compiled kernel"
+        crops = [(0, 0), (S // 2 - 16, S // 2 - 128), (S - 32, S - 256), (0, S - 256), (S - 32, 0)]
+        for (y, x) in crops:
+            ca = [p[y:y + 32, x:x + 256].copy() for p in a]
+            cb = [p[y:y + 32, x:x + 256].copy() for p in b]
+            assert_planes([p[y:y + 32, x:x + 256] for p in got], orc.chain32(ca, cb, 32), what="%d^2 crop %d,%d" % (S, y, x))
+        del got, lg, tp
+        if S == 4096:
+            # config #4 on one GPU: 8 branches + add tree = ONE launch of a program that reads 16 planes per channel
+            from rank_scenarios import config4_graph
+            import json
+            graph, root = config4_graph()
+            imgs = {e: [splitmix_plane(0x5EED0100 + e, c, S, S) for c in range(4)] for e in range(16)}
+            tp = kc.TextureProcessor.new()
+            lg = tp.new_live_graph()
+            lg.set_node_graph(kc.NodeGraph.from_json(json.dumps(graph)))
+            for e, planes in imgs.items():
+                lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_planes(planes)), e)
+            n0 = kc.stats_counter("wide_launches")
+            got = lg.await_clean(root).slot_data(root, 0).image.planes()
+            assert kc.stats_counter("wide_launches") == n0 + 1
+            for (y, x) in crops:
+                parts = [orc.chain32([p[y:y + 32, x:x + 256].copy() for p in imgs[2 * k]], [p[y:y + 32, x:x + 256].copy() for p in imgs[2 * k + 1]], 16)[:3]
+                         for k in range(8)]
+                while len(parts) > 1:
+                    parts = [[orc.mix_plane("Add", parts[i][c], parts[i + 1][c]) for c in range(3)] for i in range(0, len(parts), 2)]
+                assert_planes([p[y:y + 32, x:x + 256] for p in got[:3]], parts[0], what="config #4 4096^2 crop %d,%d" % (y, x))
+    finally:
+        kc.set_specialize(mode, 2)
