@@ -36,8 +36,9 @@
 //     one GPU    sum of the node weights
 //     branches   the list schedule's finish time, transfers charged (above)
 //     bands      (sum of the node weights) / world  +  (transfer of the result) / world
-// Config #4 (eight 16-node branches + add tree at 4096 x 4096, 8 GPUs): 8.4 / 53 / 2.6 units -> bands; on 2 GPUs 8.4 / 15 / 10.2
-// -> one GPU.  A linear chain whose result must end on one GPU never pays (the result's transfer alone costs more than the
+// Config #4 (eight 16-node branches + add tree at 4096 x 4096): one GPU 5.1 units (one launch: 16 sources read once), bands
+// 8.6 / 5.7 / 4.3 / 2.1 on 2 / 3 / 4 / 8 GPUs, branches 13-53: one GPU up to three ranks, bands from four on -- which is what the
+// measured 0.555 ms of the single launch and 192 MB / ranks over a 153 GB/s link give.  A linear chain whose result must end on one GPU never pays (the result's transfer alone costs more than the
 // chain): kc_partition_set_gather(plan, 0) leaves the bands where they are, for consumers that are row-parallel too.
 #include <algorithm>
 
@@ -284,6 +285,21 @@ int partition_plan(kc_live_graph &lg, uint32_t root, int world, int policy, kc_p
     for (auto &c : comps) {
         single += std::max(c.weight, 1.0 / 64.0);
         branches = std::max(branches, c.finish);
+    }
+    // On ONE rank a graph that is pointwise from its sources to the requested node runs as one launch when nothing is cached
+    // (joined chains, up to KC_CHAIN_MAX_IN planes per channel: csrc/runtime.cpp): it reads every source once and writes the
+    // result once, whatever the number of nodes -- config #4's 135 nodes are 204 B/px, not the 304 the per-component sum gives.
+    // In units of 40 B/px:
+    if (!lg.use_cache) {
+        uint32_t sources = 0;
+        bool pointwise = true;
+        for (size_t i = 0; i < n; ++i) {
+            const Node &nd = *g.find(topo[i]);
+            if (kind[i] == SOURCE) ++sources;
+            else if (kind[i] == COMPUTE)
+                pointwise &= nd.type == KC_NODE_MIX || nd.type == KC_NODE_SEPARATE_RGBA || nd.type == KC_NODE_COMBINE_RGBA || nd.is_output();
+        }
+        if (pointwise && sources >= 1 && sources <= (uint32_t)KC_CHAIN_MAX_IN) single = std::min(single, (3.0 * sources + 3.0) * 4.0 / 40.0);
     }
     bool all_home = P->xfers.empty();
     for (size_t i = 0; i < n; ++i) all_home &= kind[i] != COMPUTE || rank[i] == home;

@@ -77,18 +77,18 @@ def test_config4_by_row_bands_512(world, specialize):
     check_home_result(outs, oracle_result("config4", 512, 512), "config #4 by row bands, %d ranks" % world)
 
 
-def test_auto_keeps_config4_on_one_gpu_with_two_ranks_and_takes_bands_with_three():
+def test_auto_keeps_config4_on_one_gpu_with_three_ranks_and_takes_bands_with_four():
     import kanter_core_amd as kc
     want = oracle_result("config4", 128, 128)
-    outs = run_ranks(2, "evaluate_plan", name="config4", h=128, w=128, policy=kc.PartitionPolicy.Auto)
+    outs = run_ranks(3, "evaluate_plan", name="config4", h=128, w=128, policy=kc.PartitionPolicy.Auto)
     assert all(o["kind"] == kc.PlanKind.Single for o in outs), outs[0]["estimates"]
     assert sum(o["stats"]["planes_received"] for o in outs) == 0
-    check_home_result(outs, want, "config #4, auto, 2 ranks")
-    outs = run_ranks(3, "evaluate_plan", name="config4", h=128, w=128, policy=kc.PartitionPolicy.Auto)
+    check_home_result(outs, want, "config #4, auto, 3 ranks")
+    outs = run_ranks(4, "evaluate_plan", name="config4", h=128, w=128, policy=kc.PartitionPolicy.Auto)
     assert all(o["kind"] == kc.PlanKind.Bands for o in outs), outs[0]["estimates"]
     est = outs[0]["estimates"]
     assert est["bands"] < est["single"] <= est["branches"]
-    check_home_result(outs, want, "config #4, auto, 3 ranks")
+    check_home_result(outs, want, "config #4, auto, 4 ranks")
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -362,7 +362,8 @@ def test_partitioned_evaluation_over_gloo_equals_single_process(world, which):
 def test_auto_prices_one_gpu_branches_and_row_bands_for_config4():
     """BASELINE config #4 (eight 16-node branches + add tree): every node is pointwise (src/node/mix.rs:136-192), so a band plan
     moves only 1/world of the result per rank.  With the default rates (153 GB/s per link, 6.1 TB/s of HBM) that beats one GPU
-    from three ranks on; branches never do (each branch result is a whole image over one link)."""
+    -- which runs the whole graph as ONE launch, 16 sources read once -- from four ranks on; branches never do (each branch
+    result is a whole image over one link)."""
     from rank_scenarios import case
     graph, root, sizes = case("config4", 4096, 4096)
     lg = host_live_graph(graph)
@@ -372,7 +373,8 @@ def test_auto_prices_one_gpu_branches_and_row_bands_for_config4():
     for eid, (h, w) in sizes.items():  # constant placeholders carry the sizes: all a plan needs
         lg.embed_slot_data_with_id(kc.SlotData(0, 0, kc.SlotImage.from_value((w, h), 0.0, True)), eid)
     kinds = {world: lg.partition(root, world, kc.PartitionPolicy.Auto) for world in (1, 2, 3, 4, 8)}
-    assert [kinds[w].kind for w in (1, 2, 3, 4, 8)] == [kc.PlanKind.Single, kc.PlanKind.Single, kc.PlanKind.Bands, kc.PlanKind.Bands, kc.PlanKind.Bands]
+    assert [kinds[w].kind for w in (1, 2, 3, 4, 8)] == [kc.PlanKind.Single, kc.PlanKind.Single, kc.PlanKind.Single, kc.PlanKind.Bands, kc.PlanKind.Bands]
+    assert abs(kinds[8].estimates["single"] - (3 * 16 + 3) * 4 / 40) < 1e-9  # one launch: every source once + the result
     p8 = kinds[8]
     assert p8.transfers == [] and p8.full_size == (4096, 4096) and p8.bands == [(512 * r, 512 * (r + 1)) for r in range(8)]
     assert all(r == -1 for (_, r, _, _) in p8.nodes)
@@ -385,10 +387,12 @@ def test_auto_prices_one_gpu_branches_and_row_bands_for_config4():
     assert lg.partition(root, 3, kc.PartitionPolicy.Bands).bands == [(0, 13), (13, 25), (25, 37)]
     with pytest.raises(kc.TexProError):  # fewer rows than ranks
         lg.partition(root, 16, kc.PartitionPolicy.Bands) if False else lg.partition(root, 64, kc.PartitionPolicy.Bands)
-    # a slower link makes the bands lose to one GPU again
-    kc.set_option("link_gbps", 20)
+    # a slower link makes the bands lose to one GPU again, a faster one makes them win earlier
     try:
-        assert lg.partition(root, 3, kc.PartitionPolicy.Auto).kind == kc.PlanKind.Single
+        kc.set_option("link_gbps", 20)
+        assert lg.partition(root, 8, kc.PartitionPolicy.Auto).kind == kc.PlanKind.Single
+        kc.set_option("link_gbps", 600)
+        assert lg.partition(root, 3, kc.PartitionPolicy.Auto).kind == kc.PlanKind.Bands
     finally:
         kc.set_option("link_gbps", 153)
 
