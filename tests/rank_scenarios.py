@@ -176,3 +176,30 @@ def silent_peer(kc, rank, world):
     if rank == 0:
         lg.exchange([(src, 0, 1, 0)])
     return "no error"
+
+
+def fuzz_plans(kc, rank, world, seeds):
+    """Seeded random graphs (tests/test_gpu_fuzz_graphs.py: every node type, resize policies and filters, aliasing, constants,
+    sources of different sizes and types) through the partitioned path: a branch plan, and a band plan where the band walk takes
+    the graph.  Every rank embeds every source here (what a rank may NOT hold is tested by evaluate_plan); what is under test is
+    the plan and the exchange on arbitrary shapes: multi-level transfers, slots with consumers on several ranks, Separate's
+    four slots, gray / rgba / constant planes, resizes of slots that arrived from another rank."""
+    from oracle import oracle as orc  # only to let the shared builder construct its (unused) reference graph
+    from test_gpu_fuzz_graphs import _build
+    out = {}
+    for seed in seeds:
+        res = {}
+        for name, policy in (("spread", kc.PartitionPolicy.Spread), ("bands", kc.PartitionPolicy.Bands)):
+            lg, _, requested = _build(kc, orc, seed)
+            root = int(requested[0])
+            try:
+                plan = lg.partition(root, world, policy)
+            except kc.TexProError as e:  # host-only and deterministic: the same on every rank
+                res[name] = "no plan: %s" % e.kind
+                continue
+            img = lg.evaluate_partitioned(plan, root)
+            res[name] = {"kind": plan.kind, "transfers": len(plan.transfers), "levels": plan.levels,
+                         "planes": None if img is None else [p.tobytes() for p in img.planes()],
+                         "shape": None if img is None else img.planes()[0].shape}
+        out[seed] = res
+    return out

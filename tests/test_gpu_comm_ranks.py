@@ -134,3 +134,48 @@ def test_a_silent_peer_is_a_timeout_not_a_hang():
     res = run_ranks_expect_failure(2, "silent_peer")
     assert res[0][0] == "error" and "timed out" in res[0][1]
     assert res[1][0] == "ok"
+
+
+def test_random_graphs_through_branch_and_band_plans():
+    """40 seeded random graphs, 3 processes: the home rank's result of a branch plan, and of a band plan where one exists, equals the
+    oracle's literal process_node evaluation bit for bit."""
+    import kanter_core_amd as kc
+    from oracle import oracle as orc
+    from test_gpu_fuzz_graphs import _build
+    kc.init(0)
+    seeds, want = [], {}
+    for seed in range(0xF0440000, 0xF0440000 + 400):
+        _, ref, requested = _build(kc, orc, seed)
+        root = int(requested[0])
+        try:
+            sds = ref.node_slot_datas(root)
+        except (RuntimeError, AssertionError):
+            continue  # the reference fails this node (mixed types ...): covered by test_gpu_fuzz_graphs, not a case for the exchange
+        if not sds:
+            continue
+        first = sorted(sds, key=lambda s: s.slot_id)[0]
+        seeds.append(seed)
+        want[seed] = [np.ascontiguousarray(p).tobytes() for p in first.image.planes]
+        if len(seeds) == 40:
+            break
+    outs = run_ranks(3, "fuzz_plans", timeout=600, seeds=seeds)
+    n_branch = n_band = n_moved = 0
+    for seed in seeds:
+        for name in ("spread", "bands"):
+            r0 = outs[0][seed][name]
+            assert all(type(o[seed][name]) is type(r0) for o in outs), (hex(seed), name)
+            if isinstance(r0, str):
+                continue
+            assert all(o[seed][name]["planes"] is None for o in outs[1:])
+            got = r0["planes"]
+            assert got is not None and len(got) == len(want[seed]), (hex(seed), name)
+            for c, (g, x) in enumerate(zip(got, want[seed])):
+                if g != x:
+                    ga, xa = np.frombuffer(g, np.uint32), np.frombuffer(x, np.uint32)
+                    nan_ok = (ga == xa) | (np.isnan(ga.view(np.float32)) & np.isnan(xa.view(np.float32)))
+                    assert nan_ok.all(), "seed %x, %s plan (kind %d, %d transfers, %d levels), channel %d: %d pixels differ" % (
+                        seed, name, r0["kind"], r0["transfers"], r0["levels"], c, int((~nan_ok).sum()))
+            n_branch += name == "spread"
+            n_band += name == "bands"
+            n_moved += r0["transfers"] > 0
+    assert n_branch >= 30 and n_band >= 10 and n_moved >= 10, (n_branch, n_band, n_moved)

@@ -108,13 +108,20 @@ def test_a_tree_over_four_chains_on_two_sources_is_one_launch(kc, orc):
     assert_planes(got[0], got[1], what="join off == join on")
 
 
-@pytest.mark.parametrize("mode", [2, 1, 0])
-def test_config4_tree_with_and_without_its_kernels(kc, orc, mode):
+@pytest.mark.parametrize("mode,cache", [(2, True), (1, True), (1, False), (0, True)])
+def test_config4_tree_with_and_without_its_kernels(kc, orc, mode, cache, tmp_path):
     """BASELINE config #4's shape: 8 branches + a Mix(Add) tree.  mode 2: every program compiled at first sight -- ONE launch
     instead of 9; mode 1 (the default): the first evaluations fall back (the second chain runs on its own), later ones use the
-    kernels; mode 0: no joins are made."""
+    kernels -- with no kernel cache anywhere the very first evaluation does not even try (plain chains), with one it does, in the
+    hope of finding the programs' code objects there; mode 0: no joins are made."""
     h, w = 24, 72
-    sub_nodes = 16 if mode != 1 else 14  # (the specialiser's cache outlives a test: mode 1 gets programs nobody has compiled yet)
+    # (the specialiser's memory outlives a test: the mode-1 cases get programs nobody has compiled yet)
+    sub_nodes = 16 if mode != 1 else (14 if cache else 12)
+    if mode == 1:
+        kc.specialize_wait()
+        kc.kernel_cache_set_dir(str(tmp_path) if cache else "off")
+        if cache:
+            (tmp_path / ".populated").write_text("")  # a cache that holds something, though not these programs
     sources = [(synthetic_rgba(SEED_A + 10 + k, h, w), synthetic_rgba(SEED_B + 10 + k, h, w)) for k in range(8)]
     want = fanin_oracle(orc, sources, sub_nodes)
     kc.set_option("join", 1)
@@ -138,13 +145,19 @@ def test_config4_tree_with_and_without_its_kernels(kc, orc, mode):
             assert launches == [1] * 5 and fallbacks == [0] * 5, (launches, fallbacks)
         elif mode == 0:
             assert launches == [9] * 5 and fallbacks == [0] * 5, (launches, fallbacks)
-        else:
-            # the first evaluation builds plain chains (a one-shot evaluation gains nothing from programs it cannot compile in
-            # time), the second meets programs without kernels, later ones have them
+        elif not cache:
+            # no kernel cache: the first evaluation builds plain chains (a one-shot evaluation gains nothing from programs it cannot
+            # compile in time), the second meets programs without kernels, later ones have them
             assert launches[0] == 9 and fallbacks[0] == 0 and fallbacks[1] > 0 and launches[-1] == 1 and fallbacks[-1] == 0, (launches, fallbacks)
+        else:
+            # a kernel cache that might hold the programs: the first evaluation builds them, finds nothing and falls back
+            assert fallbacks[0] > 0 and launches[0] >= 9 and launches[-1] == 1 and fallbacks[-1] == 0, (launches, fallbacks)
     finally:
         kc.set_option("replay", 1)
         kc.set_specialize(1)
+        if mode == 1:
+            kc.specialize_wait()
+            kc.kernel_cache_set_dir(None)
 
 
 def test_join_then_replay(kc, orc):
