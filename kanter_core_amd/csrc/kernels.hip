@@ -971,11 +971,28 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
     }
     __syncthreads();  // the strip's horizontal taps
     if (!has_band) return;
-    float W[A][RT];
+    // The A RT weights, two to a VECTOR register pair (the same values in every lane); either half of a pair is broadcast to both
+    // lanes of a packed multiply by op_sel, at no cost.  As scalar registers -- rounds 2 and 3 -- the compiler wanted every
+    // weight as an SGPR PAIR (w, w) for v_pk_mul_f32: 96 scalar registers at ratio 8, which do not exist, so it parked them in
+    // the lanes of two vector registers and fetched each pair back with two v_readlane and a wait state before its multiply:
+    // 112 of the 304 vector instructions of a trip (208 now; Gaussian 8:1 30.4 -> 27.7 us, Lanczos3 4:1 22.2 -> 21.1:
+    // profiles/r04_poly_weights.md).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 Wp[A][RT / 2];
 #pragma unroll
     for (int a = 0; a < A; ++a)
 #pragma unroll
-        for (int u = 0; u < RT; ++u) W[a][u] = V.w[(size_t)B.ya * V.stride + a * RT + u];  // scalar registers (vector ones measured slower)
+        for (int u = 0; u < RT; u += 2)
+            Wp[a][u / 2] = f2{ V.w[(size_t)B.ya * V.stride + a * RT + u], V.w[(size_t)B.ya * V.stride + a * RT + u + 1] };
+    auto mad = [&](f4 &sum, const f4 &p, int a, int u) {
+        // (the empty statement keeps the pair where it is and the broadcast inside the loop: hoisted out of it, the 48 splats
+        // would be 96 more registers -- tried: 303 VGPRs, slower)
+        asm volatile("" : "+v"(Wp[a][u / 2]));
+        const f2 wp = Wp[a][u / 2];
+        const f2 w2 = (u & 1) ? __builtin_shufflevector(wp, wp, 1, 1) : __builtin_shufflevector(wp, wp, 0, 0);
+        const f2 lo = f2{ p.x, p.y } * w2, hi = f2{ p.z, p.w } * w2;
+        sum = f4{ sum.x + lo.x, sum.y + lo.y, sum.z + hi.x, sum.w + hi.y };
+    };
     float *ring = S.tmp + wave * 4u * S.row_floats;
     float *ringq = ring + 4u * q + (q >> 3);  // swizzled: a quad never straddles a multiple of 32
     f4 acc[A];
@@ -995,13 +1012,13 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
 #pragma unroll
             for (int u = 0; u < RT; ++u)
 #pragma unroll
-                for (int a = 0; a < A; ++a) acc[a] += p[u] * W[a][u];
+                for (int a = 0; a < A; ++a) mad(acc[a], p[u], a, u);
         } else {
 #pragma unroll
             for (int a = 0; a < A; ++a)
                 if (c >= (uint32_t)a && c - (uint32_t)a < ROWS) {
 #pragma unroll
-                    for (int u = 0; u < RT; ++u) acc[a] += p[u] * W[a][u];
+                    for (int u = 0; u < RT; ++u) mad(acc[a], p[u], a, u);
                 }
         }
         if (c >= (uint32_t)(A - 1)) {
