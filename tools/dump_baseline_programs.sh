@@ -26,7 +26,7 @@ d=$(mktemp -d)
 KC_KERNEL_CACHE_DIR="$d" python tools/band_programs.py
 rm -rf "$d"
 d=$(mktemp -d)
-KC_KERNEL_CACHE_DIR="$d" python -c "import __graft_entry__ as g; g.smoke()" > /dev/null
+KC_SPECIALIZE=2 KC_KERNEL_CACHE_DIR="$d" python -c "import __graft_entry__ as g; g.smoke()" > /dev/null   # (compile at first sight: smoke sees every program once)
 rm -rf "$d"
 sort -u "$out" -o "$out"
 wc -l "$out"
