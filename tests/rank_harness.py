@@ -6,7 +6,7 @@ and sends its (picklable) result back.  A child that fails sends its traceback; 
 import os
 import traceback
 
-import torch.multiprocessing as mp
+import multiprocessing as mp
 
 
 def _child(rank, world, comm_id, fn_name, kwargs, q, env):

@@ -53,10 +53,11 @@ def config4_graph(n_branches=8, n_nodes=16, small_source_in=None, h2n_in=None):
 
 def case(name, h, w):
     """-> (graph dict, root, {embed id: (height, width)})"""
-    from test_multi_gpu_gloo import diamond_fanin_broadcast_graph, fanin_graph
     if name == "diamond":
+        from test_multi_gpu_gloo import diamond_fanin_broadcast_graph
         graph, root, _ = diamond_fanin_broadcast_graph()
     elif name == "fanin":
+        from test_multi_gpu_gloo import fanin_graph
         graph, root = fanin_graph(8, 4)
     elif name == "config4":
         graph, root = config4_graph()
