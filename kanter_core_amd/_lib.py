@@ -236,12 +236,15 @@ def load():
     """Loads the HIP library.  Raises ImportError when it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        # KC_LIB_PATH: a tuning build of the same library (tools/build_variant.sh) instead of the shipped one -- A/B runs point the
+        # loader at the variant, nothing is copied over the product
+        path = os.environ.get("KC_LIB_PATH") or LIB_PATH
+        if not os.path.exists(path):
             raise ImportError(
                 "kanter_core_amd: %s is missing. Build it with `python -m kanter_core_amd.build` "
-                "(hipcc --offload-arch=gfx950). There is no CPU / pure-Python fallback." % LIB_PATH)
+                "(hipcc --offload-arch=gfx950). There is no CPU / pure-Python fallback." % path)
         _share_hip_runtime_with_torch()
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

@@ -931,6 +931,15 @@ struct PolyBands {
     uint32_t ty0[4], th[4];  // general tiles: first row, rows (<= 16)
 };
 
+#ifdef KC_POLY_TIMING
+#include <cstdio>
+// Tuning builds only (tools/build_variant.sh poly_timing -DKC_POLY_TIMING): where a band wave's clocks go, summed over the waves of
+// a launch: [0] waiting for a trip's rows, [1] the trip's arithmetic, [2] ring writes, [3] horizontal passes, [4] whole band,
+// [5] band waves, [6] trips.  launch_resize_poly prints and clears them when KC_POLY_TIMING is set in the environment.
+__device__ unsigned long long kc_poly_timing[8];
+#define KC_POLY_CLOCK(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); var = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
+#endif
+
 template <int A, int RT>
 __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
                                                           TapsDev H, uint32_t tile_w, uint32_t ncp, PolyBands B, XcdOrder X)
@@ -999,10 +1008,21 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
 #pragma unroll
     for (int a = 0; a < A; ++a) acc[a] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
     const uint32_t TRIPS = ROWS + A - 1;
+#ifdef KC_POLY_TIMING
+    unsigned long long tm_wait = 0, tm_arith = 0, tm_ring = 0, tm_h = 0, tm_begin, tm0, tm1, tm2, tm3, tm4;
+    KC_POLY_CLOCK(tm_begin);
+#endif
     for (uint32_t c = 0; c < TRIPS; ++c) {
         f4 p[RT];
+#ifdef KC_POLY_TIMING
+        KC_POLY_CLOCK(tm0);
+#endif
 #pragma unroll
         for (int u = 0; u < RT; ++u) p[u] = pn[u];
+#ifdef KC_POLY_TIMING
+        asm volatile("" : "+v"(p[0]), "+v"(p[RT - 1]));
+        KC_POLY_CLOCK(tm1);
+#endif
         if (c + 1u < TRIPS) {
 #pragma unroll
             for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)((c + 1u) * RT + u) * sp4];
@@ -1021,6 +1041,11 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
                     for (int u = 0; u < RT; ++u) mad(acc[a], p[u], a, u);
                 }
         }
+#ifdef KC_POLY_TIMING
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[A - 1]));
+        KC_POLY_CLOCK(tm2);
+        tm3 = tm4 = tm2;
+#endif
         if (c >= (uint32_t)(A - 1)) {
             const uint32_t k = c - (uint32_t)(A - 1);  // this row of the band is complete
             if (q_ok) {
@@ -1030,6 +1055,10 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
                 o[2] = acc[A - 1].z;
                 o[3] = acc[A - 1].w;
             }
+#ifdef KC_POLY_TIMING
+            KC_POLY_CLOCK(tm3);
+            tm4 = tm3;
+#endif
             if ((k & 3u) == 3u) {
                 // the ring is this wave's own: its lanes' writes only have to be ordered before its lanes' reads
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1038,12 +1067,34 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
                 if (lane < S.tw) resize_down_hrows(S, ring, lane, dst + (size_t)(yf + k - 3u) * dpitch, dpitch, 4u);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+#ifdef KC_POLY_TIMING
+                KC_POLY_CLOCK(tm4);
+#endif
             }
         }
+#ifdef KC_POLY_TIMING
+        tm_wait += tm1 - tm0;
+        tm_arith += tm2 - tm1;
+        tm_ring += tm3 - tm2;
+        tm_h += tm4 - tm3;
+#endif
 #pragma unroll
         for (int a = A - 1; a > 0; --a) acc[a] = acc[a - 1];
         acc[0] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
     }
+#ifdef KC_POLY_TIMING
+    if (lane == 0) {
+        unsigned long long tm_end;
+        KC_POLY_CLOCK(tm_end);
+        atomicAdd(&kc_poly_timing[0], tm_wait);
+        atomicAdd(&kc_poly_timing[1], tm_arith);
+        atomicAdd(&kc_poly_timing[2], tm_ring);
+        atomicAdd(&kc_poly_timing[3], tm_h);
+        atomicAdd(&kc_poly_timing[4], tm_end - tm_begin);
+        atomicAdd(&kc_poly_timing[5], 1ull);
+        atomicAdd(&kc_poly_timing[6], (unsigned long long)TRIPS);
+    }
+#endif
 }
 
 // Fused resample + Mix chain: phase 2's four results are input slot K-1 of the chain program, the
@@ -1242,6 +1293,18 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     if (ages == 2) launch_resize_poly_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
     else if (ages == 4) launch_resize_poly_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
     else launch_resize_poly_a<6>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
+#ifdef KC_POLY_TIMING
+    if (std::getenv("KC_POLY_TIMING")) {
+        unsigned long long t[8] = {}, zero[8] = {};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(kc_poly_timing), sizeof t);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(kc_poly_timing), zero, sizeof zero);
+        if (t[5])
+            std::fprintf(stderr, "poly timing A=%u R=%u rows=%u: %llu band waves, %.1f trips each; clocks per wave: rows-wait %.0f, arithmetic %.0f, ring %.0f, "
+                                 "horizontal %.0f, band total %.0f\n", ages, ratio, b.rows, t[5], (double)t[6] / t[5], (double)t[0] / t[5], (double)t[1] / t[5],
+                         (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5]);
+    }
+#endif
     return hipGetLastError();
 }
 
