@@ -184,6 +184,7 @@ struct TapsHost {
     std::vector<float> d2_hw;
     bool d2_want = false;  // a down-sampling axis with windows of at least 4 taps
     uint32_t d2_nc = 0, d2_hstride = 0, d2_tile_w = 0;
+    uint32_t p2_tile_w = 0;  // as the HORIZONTAL table of resize_poly2_kernel: the strip width (<= 128) whose widest window is 64 quads
     const uint32_t *d2_vrec_dev = nullptr, *d2_strips_dev = nullptr;
     const float *d2_hw_dev = nullptr;
 };
@@ -224,6 +225,8 @@ struct Context {
     bool fusion = true;
     bool replay = true;  // an evaluation that repeats the recorded one is replayed without the walk (kc_set_option("replay", 0); env KC_REPLAY)
     int down2 = 1;       // resize_down2_kernel: 0 off, 1 except where resize_poly_kernel runs at ratio 4 or 8, 2 there too (kc_set_option("down2"); env KC_DOWN2)
+    int poly2 = 1;            // integer-ratio down-sampling through resize_poly2_kernel (kc_set_option("poly2"); env KC_POLY2); 0: resize_poly_kernel / down2 as before
+    int poly2_min_ratio = 8;  // ... from this vertical ratio on (kc_set_option("poly2_min_ratio"); env KC_POLY2_MIN_RATIO): where it measures faster
     bool plain_chains = false;  // set during a graph's first evaluation: chains as the interpreter runs them (4 planes, no joins)
     bool wide = true;    // chains of up to KC_CHAIN_MAX_IN input planes (compiled kernels only); 0: KC_CHAIN_INTERP_IN as before (kc_set_option("wide"); env KC_WIDE)
     bool join = true;    // a Mix of two unevaluated chains keeps both in one program (kc_set_option("join", 0); env KC_JOIN)

@@ -1308,6 +1308,331 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     return hipGetLastError();
 }
 
+// Integer-ratio down-sampling, two waves to a band's strip (round 4).
+//
+// resize_poly_kernel's geometry is what the memory system likes -- 256-column windows, one wave-wide row request per source row
+// (profiles/tile_read_bench.hip: the bare access pattern of Gaussian 4096^2 -> 512^2 takes 15.6 us) -- but a band wave of its
+// lives 27 us: a launch has about one wave per SIMD, and that wave's own instruction stream (the trips' packed arithmetic, then
+// the horizontal pass) is the critical path.  Narrower strips give more and lighter waves and lose it all again on the wider
+// halo (128-column windows: the bare pattern alone is 22.6 us).  So the strip stays and its work is cut in two along the
+// columns: waves 2 p and 2 p + 1 of a workgroup take the left and right 128 columns of pair p's window as 8-byte lanes (half
+// the arithmetic per trip each), both write their halves of each finished row into ONE ring in LDS, and after every fourth row
+// the two share the horizontal pass -- one output pixel per lane, (row, column) = pair lane / strip width -- behind a single
+// s_barrier (the ring holds eight rows, so nobody has to wait for the other's reads before writing on).  The barrier is a bare
+// s_waitcnt lgkmcnt(0) + s_barrier: the rows requested for the next trips stay in flight across it.  Both pairs of a workgroup
+// work on the same band (same number of trips and barriers).  Same taps in the same order: same roundings.
+// Rows outside the regular range run as resize_down_kernel tiles in the launch's last workgroups, as before.
+struct Poly2Bands {
+    uint32_t ya, yb, rows, n_bands;
+    uint32_t tw, n_strips;     // band path: output columns per strip (its source window is at most 256 columns), strips per row
+    uint32_t n_wgx;            // workgroups per band (two strips each)
+    uint32_t n_band_wgs;       // n_wgx * n_bands; the general tiles follow
+    uint32_t gen_tw, gen_gx, gen_ncp;  // general tiles: resize_down_kernel's strip width, strips per row, padded window
+    uint32_t n_gen;
+    uint32_t ty0[6], th[6];
+};
+#define KC_POLY2_RING_PITCH 265u  // 256 columns + one pad per 32, odd
+#ifndef KC_POLY2_NB
+#define KC_POLY2_NB 1  // trips of rows in flight beyond the one in use: 1 / 2 / 3 measure the same or worse (profiles/r04_poly2_sweep.txt)
+#endif
+// (LDS writes of this wave done, then the workgroup's barrier; global loads stay in flight)
+#define KC_POLY2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int A, int RT>
+__global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V, TapsDev H,
+                                                           Poly2Bands B, uint32_t pair_floats, XcdOrder X)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float *__restrict__ src = P.src[blockIdx.z];
+    float *__restrict__ dst = P.dst[blockIdx.z];
+    const uint32_t spitch = P.spitch[blockIdx.z], dpitch = P.dpitch[blockIdx.z];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t wg = blockIdx.x;
+    if (X.per) {  // workgroups in XCD order (kc_internal.hpp): the bands of one strip pair meet in one L2
+        if (wg < 8u * X.per) {
+            const uint32_t tile = (wg & 7u) * X.per + (wg >> 3);
+            if (tile >= X.n) return;
+            const uint32_t wx = __umulhi(tile, X.magic);
+            wg = (tile - wx * X.gy) * B.n_wgx + wx;
+        } else {
+            wg = wg - 8u * X.per + B.n_band_wgs;
+        }
+    }
+    if (wg >= B.n_band_wgs) {
+        // rows near the border: the general form, all four waves on one tile
+        const uint32_t g = wg - B.n_band_wgs;
+        const uint32_t t = g / B.gen_gx, bx = g - t * B.gen_gx;
+        const DownStrip S = resize_down_stage(lds, H, dw, B.gen_tw, 16u, B.gen_ncp, bx);
+        resize_down_tile<4>(S, src, spitch, dst, dpitch, B.ty0[t], B.th[t], V, wave, lane);
+        return;
+    }
+    // ---- a band workgroup: strips 2 wgx, 2 wgx + 1 of band `band` (an odd strip count: the last strip twice, same values) ----
+    const uint32_t band = wg / B.n_wgx, wgx = wg - band * B.n_wgx;
+    const uint32_t pair = wave >> 1, half = wave & 1u;
+    const uint32_t strip = min(2u * wgx + pair, B.n_strips - 1u);
+    const uint32_t x0 = strip * B.tw, x1 = min(x0 + B.tw, dw), tw = x1 - x0;
+    const uint32_t c0 = H.left[x0] & ~3u;
+    const uint32_t ncols = H.left[x1 - 1] + H.count[x1 - 1] - c0;  // <= 256 (host-checked)
+    const uint32_t npairs = (ncols + 1u) / 2u;
+    float *ring = lds + pair * pair_floats;                        // 8 rows x KC_POLY2_RING_PITCH
+    uint32_t *hl = reinterpret_cast<uint32_t *>(ring + 8u * KC_POLY2_RING_PITCH);
+    uint32_t *hn = hl + 128;
+    float *hw = reinterpret_cast<float *>(hn + 128);               // tw x hsp
+    const uint32_t hsp = H.stride | 1u;  // odd pitch: the lanes' weight rows start on different banks
+    const uint32_t yf = B.ya + B.rows * band;
+    const uint32_t ROWS = min(B.rows, B.yb - yf);
+    const uint32_t sp2 = spitch / 2u;
+    const uint32_t pl = half * 64u + lane;  // lane of the pair
+    const bool p_ok = pl < npairs;
+    const uint32_t pq = min(pl, npairs - 1u);
+    // (a column pair's second column may be the first one past the window: inside the row or its padding, never past the pitch)
+    const f2 *col = reinterpret_cast<const f2 *>(src + c0 + (size_t)V.left[yf] * spitch) + pq;
+    // KC_POLY2_NB trips of rows in flight or in use: buffer b holds trips b, b + NB, ... -- named statically, so that the wait for
+    // a trip's rows leaves the younger trips' loads in flight
+    constexpr int NB = KC_POLY2_NB;
+    const uint32_t TRIPS = ROWS + A - 1;
+    f2 pb[NB][RT];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int u = 0; u < RT; ++u) pb[b][u] = col[(size_t)(min((uint32_t)b, TRIPS - 1u) * RT + u) * sp2];
+    // the pair's copy of its strip's horizontal taps (in flight together with the first rows)
+    for (uint32_t i = pl; i < tw; i += 128u) {
+        hl[i] = H.left[x0 + i] - c0;
+        hn[i] = H.count[x0 + i];
+    }
+    for (uint32_t i = pl; i < tw * H.stride; i += 128u) {
+        const uint32_t x = i / H.stride, j = i - x * H.stride;
+        hw[x * hsp + j] = H.w[(size_t)x0 * H.stride + i];
+    }
+    // the A RT weights, two to a vector register pair, broadcast by op_sel inside the loop (as in resize_poly_kernel)
+    f2 Wp[A][RT / 2];
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int u = 0; u < RT; u += 2)
+            Wp[a][u / 2] = f2{ V.w[(size_t)B.ya * V.stride + a * RT + u], V.w[(size_t)B.ya * V.stride + a * RT + u + 1] };
+    auto mad = [&](f2 &sum, const f2 &p, int a, int u) {
+        asm volatile("" : "+v"(Wp[a][u / 2]));
+        const f2 wp = Wp[a][u / 2];
+        sum += p * ((u & 1) ? __builtin_shufflevector(wp, wp, 1, 1) : __builtin_shufflevector(wp, wp, 0, 0));
+    };
+    const uint32_t rj = 2u * pq + ((2u * pq) >> 5);  // where this lane's pair goes in a ring row (a pair never straddles a pad)
+    // which pixel of four finished rows this lane takes in the horizontal pass: all four rows at once for strips of up to 32
+    // columns, two for up to 64, one row of up to 128 columns at a time beyond
+    const uint32_t rows_per_pass = tw <= 32u ? 4u : tw <= 64u ? 2u : 1u;  // (uniform)
+    const uint32_t hx = rows_per_pass == 4u ? (pl & 31u) : rows_per_pass == 2u ? (pl & 63u) : pl;
+    const uint32_t hr = rows_per_pass == 4u ? (pl >> 5) : rows_per_pass == 2u ? (pl >> 6) : 0u;
+    const bool h_ok = hx < tw;
+    const uint32_t hxs = h_ok ? hx : 0u;
+    f2 acc[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) acc[a] = f2{ 0.0f, 0.0f };
+    KC_POLY2_BARRIER();  // the taps are staged
+    const uint32_t hcount = hn[hxs], h0 = hl[hxs];
+    const float *hwt = hw + hxs * hsp;
+    const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)hcount);
+    const bool uniform = (nu & 3u) == 0u && __builtin_amdgcn_ballot_w64(hcount != nu) == 0ull;
+#ifdef KC_POLY_TIMING
+    unsigned long long tm_wait = 0, tm_arith = 0, tm_ring = 0, tm_h = 0, tm_begin, tm0, tm1, tm2, tm3, tm4;
+    KC_POLY_CLOCK(tm_begin);
+#endif
+    for (uint32_t cb = 0; cb < TRIPS; cb += NB) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const uint32_t c = cb + b;  // (up to NB - 1 trips past the last one do nothing: leaving the loop from its middle would join
+                                    // paths with different numbers of loads in flight, and the waits would be for all of them)
+        f2 (&p)[RT] = pb[b];
+#ifdef KC_POLY_TIMING
+        KC_POLY_CLOCK(tm0);
+        asm volatile("" : "+v"(p[0]), "+v"(p[RT - 1]));
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 1) * RT) : "memory");
+        KC_POLY_CLOCK(tm1);
+#endif
+        // age a holds row c - a of the band
+        if (c >= (uint32_t)(A - 1) && c < ROWS) {
+#pragma unroll
+            for (int u = 0; u < RT; ++u)
+#pragma unroll
+                for (int a = 0; a < A; ++a) mad(acc[a], p[u], a, u);
+        } else {
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+                if (c >= (uint32_t)a && c - (uint32_t)a < ROWS) {
+#pragma unroll
+                    for (int u = 0; u < RT; ++u) mad(acc[a], p[u], a, u);
+                }
+        }
+        // the buffer's next trip (past the last one: that one again, so that the number of loads in flight is the same on every path)
+        {
+            const uint32_t cn = min(c + (uint32_t)NB, TRIPS - 1u);
+#pragma unroll
+            for (int u = 0; u < RT; ++u) {
+                asm volatile("" : "+v"(p[u]));  // (after this trip's last use of the row, not in a register of its own)
+                p[u] = col[(size_t)(cn * RT + u) * sp2];
+            }
+        }
+#ifdef KC_POLY_TIMING
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[A - 1]));
+        KC_POLY_CLOCK(tm2);
+        tm3 = tm4 = tm2;
+#endif
+        if (c >= (uint32_t)(A - 1) && c < TRIPS) {
+            const uint32_t k = c - (uint32_t)(A - 1);  // this row of the band is complete
+            if (p_ok) {
+                float *o = ring + (k & 7u) * KC_POLY2_RING_PITCH + rj;
+                o[0] = acc[A - 1].x;
+                o[1] = acc[A - 1].y;
+            }
+#ifdef KC_POLY_TIMING
+            KC_POLY_CLOCK(tm3);
+            tm4 = tm3;
+#endif
+            if ((k & 3u) == 3u) {
+                KC_POLY2_BARRIER();  // both halves of the four rows are in the ring (and everybody is done with the four before)
+                const float *rows4 = ring + (k & 4u) * KC_POLY2_RING_PITCH;
+                for (uint32_t r0 = 0; r0 < 4u; r0 += rows_per_pass) {
+                    const float *row = rows4 + (r0 + hr) * KC_POLY2_RING_PITCH;
+                    float t = 0.0f;
+                    if (uniform) {
+                        for (uint32_t j0 = 0; j0 < nu; j0 += 4u) {
+                            float pv[4], wt[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t idx = h0 + j0 + u;
+                                pv[u] = row[idx + (idx >> 5)];
+                                wt[u] = hwt[j0 + u];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) t += pv[u] * wt[u];
+                        }
+                    } else {
+                        for (uint32_t j0 = 0; j0 < hcount; j0 += 4u) {
+                            float pv[4], wt[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t jj = min(j0 + u, hcount - 1u);
+                                const uint32_t idx = h0 + jj;
+                                pv[u] = row[idx + (idx >> 5)];
+                                wt[u] = hwt[jj];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) t += j0 + u < hcount ? pv[u] * wt[u] : -0.0f;  // -0.0 leaves the sum as it is
+                        }
+                    }
+                    if (h_ok) dst[(size_t)(yf + k - 3u + r0 + hr) * dpitch + x0 + hx] = clamp01_nan_passthrough(t);
+                }
+#ifdef KC_POLY_TIMING
+                KC_POLY_CLOCK(tm4);
+#endif
+            }
+        }
+#ifdef KC_POLY_TIMING
+        tm_wait += tm1 - tm0;
+        tm_arith += tm2 - tm1;
+        tm_ring += tm3 - tm2;
+        tm_h += tm4 - tm3;
+#endif
+#pragma unroll
+        for (int a = A - 1; a > 0; --a) acc[a] = acc[a - 1];
+        acc[0] = f2{ 0.0f, 0.0f };
+      }
+    }
+#ifdef KC_POLY_TIMING
+    if (lane == 0) {
+        unsigned long long tm_end;
+        KC_POLY_CLOCK(tm_end);
+        atomicAdd(&kc_poly_timing[0], tm_wait);
+        atomicAdd(&kc_poly_timing[1], tm_arith);
+        atomicAdd(&kc_poly_timing[2], tm_ring);
+        atomicAdd(&kc_poly_timing[3], tm_h);
+        atomicAdd(&kc_poly_timing[4], tm_end - tm_begin);
+        atomicAdd(&kc_poly_timing[5], 1ull);
+        atomicAdd(&kc_poly_timing[6], (unsigned long long)TRIPS);
+    }
+#endif
+}
+
+template <int A>
+static void launch_resize_poly2_a(dim3 grid, size_t lds, hipStream_t s, uint32_t rt, const ResizePlanes &p, uint32_t dw, uint32_t dh,
+                                  TapsDev v, TapsDev h, const Poly2Bands &b, uint32_t pair_floats, const XcdOrder &x)
+{
+    if (rt == 2) resize_poly2_kernel<A, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, b, pair_floats, x);
+    else if (rt == 4) resize_poly2_kernel<A, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, b, pair_floats, x);
+    else resize_poly2_kernel<A, 8><<<grid, 256, lds, s>>>(p, dw, dh, v, h, b, pair_floats, x);
+}
+
+// tw: output columns per band strip (host-checked: every strip's source window, from its first column rounded down to a multiple
+// of 4, is at most 256 columns); gen_tw / gen_ncp: resize_down_kernel's tile for the border rows.
+hipError_t launch_resize_poly2(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tw,
+                               uint32_t gen_tw, uint32_t gen_ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, bool xcd,
+                               hipStream_t s)
+{
+    if (dw == 0 || dh == 0) return hipSuccess;
+    if (batch < 1 || batch > 4) return hipErrorInvalidValue;
+    if (tw == 0 || tw > 128 || gen_tw == 0 || gen_tw > 64 || gen_ncp % 4 != 0 || gen_ncp > 256 || reg_a > reg_b || reg_b > dh) return hipErrorInvalidValue;
+    if ((ages != 2 && ages != 4 && ages != 6) || (ratio != 2 && ratio != 4 && ratio != 8)) return hipErrorInvalidValue;
+    Poly2Bands b{};
+    b.ya = reg_a;
+    b.yb = reg_a + (reg_b - reg_a) / 4u * 4u;
+    if (b.yb == b.ya) return hipErrorInvalidValue;
+    b.tw = tw;
+    b.n_strips = (dw + tw - 1) / tw;
+    b.n_wgx = (b.n_strips + 1u) / 2u;
+    // band height as resize_poly_kernel chooses it (a launch lasts as long as one wave lives), for twice the waves per strip
+    static const uint32_t rows_env = std::getenv("KC_POLY_ROWS") ? std::max(4u, (uint32_t)std::atoi(std::getenv("KC_POLY_ROWS")) / 4u * 4u) : 0u;
+    b.rows = 12u;
+    {
+        // (2048^2 -> 256^2 Gaussian: 16.5 / 14.7 us with 4 / 8 rows = 1280 / 640 waves)
+        const uint64_t regular = b.yb - b.ya, waves4 = 4u * b.n_wgx * ((regular + 3u) / 4u) * (uint64_t)batch,
+                       waves8 = 4u * b.n_wgx * ((regular + 7u) / 8u) * (uint64_t)batch;
+        if (waves4 <= 1100u) b.rows = 4u;
+        else if (waves8 <= 2200u) b.rows = 8u;
+    }
+    if (rows_env) b.rows = rows_env;
+    b.n_bands = (b.yb - b.ya + b.rows - 1) / b.rows;
+    b.n_band_wgs = b.n_wgx * b.n_bands;
+    b.gen_tw = gen_tw;
+    b.gen_ncp = gen_ncp;
+    b.gen_gx = (dw + gen_tw - 1) / gen_tw;
+    uint32_t nt = 0;
+    auto add_tiles = [&](uint32_t y0, uint32_t y1) {
+        for (uint32_t y = y0; y < y1; y += 16u) {
+            if (nt == 6) return false;
+            b.ty0[nt] = y;
+            b.th[nt] = std::min(16u, y1 - y);
+            ++nt;
+        }
+        return true;
+    };
+    if (!add_tiles(0, b.ya) || !add_tiles(b.yb, dh)) return hipErrorInvalidValue;
+    b.n_gen = nt;
+    const uint32_t pair_floats = (8u * KC_POLY2_RING_PITCH + 256u + tw * (h.stride | 1u) + 3u) / 4u * 4u;
+    const size_t lds = std::max((size_t)2 * pair_floats * sizeof(float), resize_down_lds_bytes(16, gen_ncp, gen_tw, h.stride));
+    if (lds > 64u * 1024u) return hipErrorInvalidValue;
+    static const int xcd_env = std::getenv("KC_POLY_XCD") ? std::atoi(std::getenv("KC_POLY_XCD")) : -1;
+    const XcdOrder x = xcd_order(b.n_wgx, b.n_bands, xcd_env < 0 ? xcd : xcd_env != 0);
+    dim3 grid((x.per ? 8u * x.per : b.n_band_wgs) + nt * b.gen_gx, 1, batch);
+    if (ages == 2) launch_resize_poly2_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, b, pair_floats, x);
+    else if (ages == 4) launch_resize_poly2_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, b, pair_floats, x);
+    else launch_resize_poly2_a<6>(grid, lds, s, ratio, p, dw, dh, v, h, b, pair_floats, x);
+#ifdef KC_POLY_TIMING
+    if (std::getenv("KC_POLY_TIMING")) {
+        unsigned long long t[8] = {}, zero[8] = {};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(kc_poly_timing), sizeof t);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(kc_poly_timing), zero, sizeof zero);
+        if (t[5])
+            std::fprintf(stderr, "poly2 timing A=%u R=%u rows=%u tw=%u: %llu band waves, %.1f trips each; clocks per wave: rows-wait %.0f, arithmetic %.0f, ring %.0f, "
+                                 "horizontal %.0f, band total %.0f\n", ages, ratio, b.rows, tw, t[5], (double)t[6] / t[5], (double)t[0] / t[5], (double)t[1] / t[5],
+                         (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5]);
+    }
+#endif
+    return hipGetLastError();
+}
+
 template <int K>
 static hipError_t launch_resize_chain_k(const ChainProgram &p, dim3 grid, size_t lds, hipStream_t s, uint32_t dw,
                                         uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w, uint32_t tile_h, uint32_t ncp)

@@ -127,11 +127,18 @@ static uint32_t tile_groups(const TapsHost &h, uint32_t out_n, uint32_t tile_w)
 // Horizontal use: rows padded to a multiple of four weights, and the strip width.
 void down2_build(uint32_t out_n, TapsHost &t)
 {
-    t.d2_nc = t.d2_hstride = t.d2_tile_w = 0;
+    t.d2_nc = t.d2_hstride = t.d2_tile_w = t.p2_tile_w = 0;
     t.d2_vrec.clear();
     t.d2_strips.clear();
     t.d2_hw.clear();
     if (!t.d2_want || out_n == 0) return;
+    // resize_poly2_kernel's strips: the widest (up to 128 columns) whose source window is at most 64 quads, evened out
+    for (uint32_t tw = std::min(128u, out_n); tw >= 1; --tw)
+        if (tile_groups(t, out_n, tw) <= 64u) {
+            const uint32_t strips = (out_n + tw - 1) / tw, even = (out_n + strips - 1) / strips;
+            t.p2_tile_w = tile_groups(t, out_n, even) <= 64u ? even : tw;
+            break;
+        }
     const uint32_t groups = (out_n + 3u) / 4u;
     uint32_t nc = 0;
     for (uint32_t g = 0; g < groups; ++g) {
@@ -619,6 +626,19 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
             // 23.5 against 26.7 us, CatmullRom 18.1 / 21.4; at ratio 2 down2 wins, 26.3 / 30.4 -- profiles/r03_down2_ab.txt)
             // tiles in XCD order while source and result stay in the Infinity Cache (the budget of the cache policy)
             const bool fits_cache = (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height) <= (208ull << 20);
+            // integer ratios: two waves to a band's strip (resize_poly2_kernel)
+            // (where it measures faster than the forms below -- profiles/r04_poly2_sweep.txt: ratio 8 with windows of 4 or 6 ages,
+            // Gaussian 4096^2 -> 512^2 27.6 -> 25.3 us, 8192^2 -> 1024^2 82.5 -> 72.5; at ratio 4 and 2 it is behind resize_poly_kernel
+            // and resize_down2_kernel, 24.8 against 21.2 us and 34.3 against 24.5; kc_set_option("poly2_min_ratio") moves the line)
+            if (t.poly && c.poly2 && tv->host.reg_ratio >= (uint32_t)c.poly2_min_ratio && tv->host.reg_ages >= 4 && th->host.p2_tile_w) {
+                hipError_t e2 = launch_resize_poly2(rp, n, size.width, size.height, tv->dev, th->dev, th->host.p2_tile_w, t.tile_w, t.ncp,
+                                                    tv->host.reg_a, tv->host.reg_b, tv->host.reg_ages, tv->host.reg_ratio, fits_cache, c.stream);
+                if (e2 != hipSuccess) return hip_fail(e2, "launch_resize_poly2");
+                c.launches++;
+                c.counters["poly2_launches"]++;
+                c.alg_bytes += (uint64_t)n * 4 * ((uint64_t)s0->w * s0->h + (uint64_t)size.width * size.height);
+                return KC_OK;
+            }
             const bool poly_first = t.poly && tv->host.reg_ratio >= 4;
             if (c.down2 > (poly_first ? 1 : 0) && tv->host.d2_nc && tv->host.d2_vrec_dev && th->host.d2_tile_w &&
                 th->host.d2_hw_dev && th->host.d2_strips_dev) {

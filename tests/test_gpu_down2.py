@@ -30,8 +30,10 @@ CASES = [
 def kc():
     import kanter_core_amd as kc
     kc.init(0)
+    kc.set_option("poly2", 0)  # this module is about resize_down2_kernel and the kernels IT replaces (tests/test_gpu_poly2.py: the pair form)
     yield kc
     kc.set_option("down2", 1)
+    kc.set_option("poly2", 1)
 
 
 @pytest.fixture(scope="module")

@@ -76,6 +76,15 @@ def test_resize_kernels_fit_their_budgets(usage):
     assert u["VGPRs"] <= 256, u
 
 
+def test_poly2_kernels_fit_their_budgets(usage):
+    # resize_poly2_kernel<A, RT>: 8-byte lanes, A * RT / 2 weight pairs + one or two trips of RT rows: four waves per SIMD at the
+    # widest instantiation, and its barrier must stay the bare one (no vmcnt(0) in front of it would show up as time, not here)
+    for frag, budget in (("resize_poly2_kernelILi6ELi8EEE", 128), ("resize_poly2_kernelILi4ELi8EEE", 128), ("resize_poly2_kernelILi6ELi4EEE", 128),
+                         ("resize_poly2_kernelILi6ELi2EEE", 96), ("resize_poly2_kernelILi2ELi8EEE", 96)):
+        (u,) = find(usage, frag)
+        assert u["VGPRs"] <= budget, (frag, u)
+
+
 def test_down2_kernels_fit_their_budgets(usage):
     # resize_down2_kernel<HC, NW4, ONE> (down2.hip): 16 source rows in flight per lane (64 VGPRs) next to 8 packed sums.  The
     # single-chunk forms must allow 4 waves per SIMD with three columns per lane (Lanczos3 at ratios below 1.6) and 5 otherwise;
