@@ -933,6 +933,21 @@ def main():
         # finished band goes to rank 0's row offset through the library's communicator (kc_comm_gather_bands), so that a multi-GPU
         # run also carries a measured transfer.  Outside the timed region above; never part of `value`.
         leg = {}
+        # This leg is the first thing in the run that makes the ranks wait for EACH OTHER'S GPUs (counters in shared memory that
+        # streams wait on): if it ever stalls, the line measured above must still come out.  Every rank arms the same timer; when
+        # it fires rank 0 prints the line with the leg marked as timed out and all ranks leave without tearing anything down.
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                out["gather_to_rank0"] = {"error": "timed out after %d s (the leg was abandoned; everything else in this line was measured before it)" % leg_limit}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        leg_limit = int(os.environ.get("KC_BENCH_LEG_TIMEOUT_S", "150"))
+        watchdog = threading.Timer(leg_limit, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             from kanter_core_amd.multi_gpu import ensure_communicator
             ensure_communicator(rank, world)
@@ -964,6 +979,13 @@ def main():
         except Exception as e:  # noqa: BLE001 -- the headline line must survive a failing side leg
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
         out["gather_to_rank0"] = leg
+        if "error" in leg:
+            # a rank that failed left the others waiting in the leg's collectives: nobody can reach the barrier below together
+            watchdog.cancel()
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog.cancel()
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -446,24 +446,28 @@ struct ResizeTile {
 
 template <int MAXT>
 struct ResizeCols {  // the 4 output columns a thread owns: window start (tile-relative), weights, which taps exist
+    typedef float f2 __attribute__((ext_vector_type(2)));
     uint32_t hl[4];
-    float wreg[4][MAXT];
+    f2 w01[MAXT], w23[MAXT];  // the weights of columns 0, 1 and 2, 3 as the packed multiply takes them
     bool live[4][MAXT];
+    uint32_t minc;  // fewest taps of the four
 };
 
 template <int MAXT>
 static __device__ __forceinline__ void resize_load_cols(ResizeCols<MAXT> &C, const TapsDev &H, uint32_t ox, uint32_t x1,
                                                         uint32_t c0)
 {
+    C.minc = 0xFFFFFFFFu;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const uint32_t x = min(ox + e, x1 - 1);
         C.hl[e] = H.left[x] - c0;
         const uint32_t hn = H.count[x];
+        C.minc = min(C.minc, hn);
         const float *wh = H.w + (size_t)x * H.stride;
 #pragma unroll
         for (int j = 0; j < MAXT; ++j) {
-            C.wreg[e][j] = wh[j];  // rows of the table are zero-padded to `stride` entries
+            (e < 2 ? C.w01[j] : C.w23[j])[e & 1] = wh[j];  // rows of the table are zero-padded to `stride` entries
             C.live[e][j] = (uint32_t)j < hn;
         }
     }
@@ -514,6 +518,21 @@ static __device__ __forceinline__ void resize_vpass_items(const f4 *__restrict__
             }
 #pragma unroll
             for (int u = 0; u < VU; ++u) add(acc, p[u], wt[u]);
+        }
+        if constexpr (VU > 4) {
+            // (windows of 5 .. 7 taps everywhere in the tile -- up-sampling with CatmullRom, Lanczos3, Gaussian: four of them need
+            // no predicate either)
+            for (; j0 + 4u <= vmin; j0 += 4u) {
+                f4 p[4];
+                float wt[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    p[u] = col[(size_t)(j0 + u) * sp4];
+                    wt[u] = w[j0 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) add(acc, p[u], wt[u]);
+            }
         }
         for (; j0 < vstride; j0 += 4u) {
             f4 p[4];
@@ -588,30 +607,46 @@ static __device__ __forceinline__ ResizeTile resize_tile_vpass(float *lds, const
     return T;
 }
 
-// Horizontal pass for one tile row and this thread's 4 columns.
+// Horizontal pass for one tile row and this thread's 4 columns.  Taps j < MINT need no predicate (every lane of the wave has
+// them); columns 0, 1 and 2, 3 go through the packed multiply and add as pairs (their weights sit in register pairs for the
+// whole tile; as four separate sums the compiler packed products of one column's neighbouring taps and then shuffled them
+// apart again for the adds: 35 moves per row and thread).
 template <int MINT, int MAXT>
 static __device__ __forceinline__ void resize_out_row(const ResizeCols<MAXT> &C, const float *row, float (&res)[4])
 {
-    {
-        // Taps are contiguous from hl[e]: one base address per output, constant offsets per tap
-        // (ds_read2).  A tap past the window reads the next floats of the LDS block -- always
-        // inside the allocation (the vertical tap table follows tmp) -- and is discarded below.
-        float t[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-        const float *pe[4] = { row + C.hl[0], row + C.hl[1], row + C.hl[2], row + C.hl[3] };
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    // Taps are contiguous from hl[e]: one base address per output, constant offsets per tap.  A tap past the window reads the
+    // next floats of the LDS block -- always inside the allocation (the vertical tap table follows tmp) -- and is discarded below.
+    f2 t01 = { 0.0f, 0.0f }, t23 = { 0.0f, 0.0f };
+    const float *pe[4] = { row + C.hl[0], row + C.hl[1], row + C.hl[2], row + C.hl[3] };
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float p = pe[e][j] * C.wreg[e][j];
-                // a tap that does not exist contributes -0.0: t + (-0.0) == t for every t
-                // (including +-0, +-inf, NaN), so the sum equals the reference's shorter sum
-                t[e] += (j < MINT || C.live[e][j]) ? p : -0.0f;
-            }
+    for (int j = 0; j < MAXT; ++j) {
+        f2 q01 = f2{ pe[0][j], pe[1][j] } * C.w01[j];
+        f2 q23 = f2{ pe[2][j], pe[3][j] } * C.w23[j];
+        if (j >= MINT) {
+            // a tap that does not exist contributes -0.0: t + (-0.0) == t for every t (including +-0, +-inf, NaN), so the sum
+            // equals the reference's shorter sum
+            q01.x = C.live[0][j] ? q01.x : -0.0f;
+            q01.y = C.live[1][j] ? q01.y : -0.0f;
+            q23.x = C.live[2][j] ? q23.x : -0.0f;
+            q23.y = C.live[3][j] ? q23.y : -0.0f;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) res[e] = clamp01_nan_passthrough(t[e]);
+        t01 += q01;
+        t23 += q23;
     }
+    res[0] = clamp01_nan_passthrough(t01.x);
+    res[1] = clamp01_nan_passthrough(t01.y);
+    res[2] = clamp01_nan_passthrough(t23.x);
+    res[3] = clamp01_nan_passthrough(t23.y);
 }
+
+// How many taps a wave may sum without a predicate: all of its lanes' columns have MAXT - 2 (windows of 6 or 8 register taps:
+// up-sampling by a non-integer ratio has 4 - 5 taps with CatmullRom, 6 - 7 with Lanczos3 / Gaussian) or MAXT - 1 (4 register
+// taps), else what the whole image guarantees.
+template <int MINT, int MAXT>
+struct ResizeUmin {
+    static constexpr int value = MAXT >= 6 ? MAXT - 2 : MAXT == 4 ? 3 : MINT;
+};
 
 template <int MINT, int MAXT>  // horizontal taps, all in registers: MINT unconditional, up to MAXT
 __global__ __launch_bounds__(256) void resize_lds_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
@@ -631,13 +666,24 @@ __global__ __launch_bounds__(256) void resize_lds_kernel(const ResizePlanes P, u
     ResizeCols<MAXT> C;
     resize_load_cols<MAXT>(C, H, ox, x1, H.left[x0] & ~3u);
     const ResizeTile T = resize_tile_vpass(lds, src, spitch, dw, dh, V, H, tile_w, tile_h, ncp);
+    constexpr int UMIN = ResizeUmin<MINT, MAXT>::value;
+    // (asked of every lane, also those without columns: their minc is that of the tile's last column)
+    const bool wave_has_umin = UMIN > MINT && __builtin_amdgcn_ballot_w64(C.minc < (uint32_t)UMIN) == 0ull;
     if (ox >= T.x1) return;
     if (ox + 3 < T.x1) {
         // interior columns: one 16-byte store per row
-        for (uint32_t ty = rg; ty < T.th; ty += row_groups) {
-            float res[4];
-            resize_out_row<MINT, MAXT>(C, T.tmp + ty * ncp, res);
-            *reinterpret_cast<float4 *>(dst + (size_t)(T.y0 + ty) * dpitch + ox) = make_float4(res[0], res[1], res[2], res[3]);
+        if (wave_has_umin) {
+            for (uint32_t ty = rg; ty < T.th; ty += row_groups) {
+                float res[4];
+                resize_out_row<UMIN, MAXT>(C, T.tmp + ty * ncp, res);
+                *reinterpret_cast<float4 *>(dst + (size_t)(T.y0 + ty) * dpitch + ox) = make_float4(res[0], res[1], res[2], res[3]);
+            }
+        } else {
+            for (uint32_t ty = rg; ty < T.th; ty += row_groups) {
+                float res[4];
+                resize_out_row<MINT, MAXT>(C, T.tmp + ty * ncp, res);
+                *reinterpret_cast<float4 *>(dst + (size_t)(T.y0 + ty) * dpitch + ox) = make_float4(res[0], res[1], res[2], res[3]);
+            }
         }
     } else {
         // the tile's last, partial quad
