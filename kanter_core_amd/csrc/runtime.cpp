@@ -128,9 +128,17 @@ int hip_fail(hipError_t e, const char *what)
 
 int need_init()
 {
-    if (!ctx().inited) {
+    Context &c = ctx();
+    if (!c.inited) {
         set_error("kc_init() has not succeeded: no gfx950 device bound (there is no CPU fallback)");
         return KC_ERR_NO_DEVICE;
+    }
+    // HIP's current device is per host thread and 0 for a new one: a call from another thread than kc_init's (or after the caller
+    // switched devices) must not allocate, launch or load code objects on a different GPU than the library's stream belongs to
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c.device) {
+        hipError_t e = hipSetDevice(c.device);
+        if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     }
     return KC_OK;
 }
