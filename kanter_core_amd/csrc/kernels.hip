@@ -975,6 +975,7 @@ struct PolyBands {
     uint32_t n_bands;
     uint32_t nyb;       // workgroups (of 4 bands) along y; the general tiles follow
     uint32_t ty0[4], th[4];  // general tiles: first row, rows (<= 16)
+    uint32_t row_major;      // with the XCD order: an XCD's eighth of the tiles runs along the rows (whole band groups), not down the strips
 };
 
 #ifdef KC_POLY_TIMING
@@ -997,6 +998,11 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
         if (tile >= X.n) return;
         bx = __umulhi(tile, X.magic);
         by = tile - bx * X.gy;
+        if (B.row_major) {  // (X was made for the transposed grid: quotient = row of tiles, remainder = strip)
+            const uint32_t t = bx;
+            bx = by;
+            by = t;
+        }
     }
     const DownStrip S = resize_down_stage(lds, H, dw, tile_w, 16u, ncp, bx);
     const float *__restrict__ src = P.src[blockIdx.z];
@@ -1005,6 +1011,9 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
     if (by >= B.nyb) {
+#ifdef KC_POLY_SKIP_GEN  // tuning builds: what the launch costs without its border tiles (their rows stay unwritten)
+        return;
+#endif
         const uint32_t t = by - B.nyb;
         resize_down_tile<4>(S, src, spitch, dst, dpitch, B.ty0[t], B.th[t], V, wave, lane);
         return;
@@ -1042,7 +1051,13 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
     auto mad = [&](f4 &sum, const f4 &p, int a, int u) {
         // (the empty statement keeps the pair where it is and the broadcast inside the loop: hoisted out of it, the 48 splats
         // would be 96 more registers -- tried: 303 VGPRs, slower)
+#ifdef KC_POLY_SKIP_ARITH  // tuning builds: the trips without their arithmetic (the rows are only touched)
+        asm volatile("" : "+v"(sum) : "v"(p));
+        return;
+#endif
+#ifndef KC_POLY_NO_ASM
         asm volatile("" : "+v"(Wp[a][u / 2]));
+#endif
         const f2 wp = Wp[a][u / 2];
         const f2 w2 = (u & 1) ? __builtin_shufflevector(wp, wp, 1, 1) : __builtin_shufflevector(wp, wp, 0, 0);
         const f2 lo = f2{ p.x, p.y } * w2, hi = f2{ p.z, p.w } * w2;
@@ -1094,7 +1109,11 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
 #endif
         if (c >= (uint32_t)(A - 1)) {
             const uint32_t k = c - (uint32_t)(A - 1);  // this row of the band is complete
+#ifdef KC_POLY_SKIP_RING
+            if (q_ok && ringq == nullptr) {
+#else
             if (q_ok) {
+#endif
                 float *o = ringq + (k & 3u) * S.row_floats;
                 o[0] = acc[A - 1].x;
                 o[1] = acc[A - 1].y;
@@ -1110,7 +1129,9 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef KC_POLY_SKIP_H  // tuning builds: the launch without its horizontal passes (nothing is written)
                 if (lane < S.tw) resize_down_hrows(S, ring, lane, dst + (size_t)(yf + k - 3u) * dpitch, dpitch, 4u);
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #ifdef KC_POLY_TIMING
@@ -1333,8 +1354,10 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     const size_t lds = resize_down_lds_bytes(16, ncp, tile_w, h.stride);
     dim3 grid((dw + tile_w - 1) / tile_w, b.nyb + nt, batch);
     // KC_POLY_XCD=0 / 1: never / always (A/B); default: the caller's hint (planes that fit the Infinity Cache)
+    // KC_POLY_XCD=2: the eighths along the rows (whole band groups per XCD), as resize_poly2_kernel has them
     static const int xcd_env = std::getenv("KC_POLY_XCD") ? std::atoi(std::getenv("KC_POLY_XCD")) : -1;
-    const XcdOrder x = xcd_order(grid.x, grid.y, xcd_env < 0 ? xcd : xcd_env != 0);
+    b.row_major = xcd_env == 2 ? 1u : 0u;
+    const XcdOrder x = b.row_major ? xcd_order(grid.y, grid.x, true) : xcd_order(grid.x, grid.y, xcd_env < 0 ? xcd : xcd_env != 0);
     if (x.per) grid = dim3(8u * x.per, 1, batch);
     if (ages == 2) launch_resize_poly_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
     else if (ages == 4) launch_resize_poly_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
@@ -1396,17 +1419,29 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t wg = blockIdx.x;
-    if (X.per) {  // workgroups in XCD order (kc_internal.hpp): the bands of one strip pair meet in one L2
+    if (X.per) {
+        // Workgroup id % 8 is the XCD.  XCD k takes the k-th eighth of the band workgroups in BAND-major order: whole bands, one
+        // after the other -- the strips of a band (which share their halo columns) and the next band (which shares 40 of its 136
+        // source rows at ratio 8) meet in one L2 while they are there, and every XCD streams one contiguous eighth of the plane.
+        // (profiles/tile_read_bench.hip, the loads and the vertical arithmetic alone: 14.1 us like this, 22.2 in plain order;
+        // KC_POLY2_XCD=2: the eighths in strip-major order, a strip pair with all its bands, as resize_poly_kernel has them)
         if (wg < 8u * X.per) {
             const uint32_t tile = (wg & 7u) * X.per + (wg >> 3);
             if (tile >= X.n) return;
-            const uint32_t wx = __umulhi(tile, X.magic);
-            wg = (tile - wx * X.gy) * B.n_wgx + wx;
+            if (X.gy) {
+                const uint32_t wx = __umulhi(tile, X.magic);
+                wg = (tile - wx * X.gy) * B.n_wgx + wx;
+            } else {
+                wg = tile;
+            }
         } else {
             wg = wg - 8u * X.per + B.n_band_wgs;
         }
     }
     if (wg >= B.n_band_wgs) {
+#ifdef KC_POLY_SKIP_GEN
+        return;
+#endif
         // rows near the border: the general form, all four waves on one tile
         const uint32_t g = wg - B.n_band_wgs;
         const uint32_t t = g / B.gen_gx, bx = g - t * B.gen_gx;
@@ -1461,6 +1496,10 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
         for (int u = 0; u < RT; u += 2)
             Wp[a][u / 2] = f2{ V.w[(size_t)B.ya * V.stride + a * RT + u], V.w[(size_t)B.ya * V.stride + a * RT + u + 1] };
     auto mad = [&](f2 &sum, const f2 &p, int a, int u) {
+#ifdef KC_POLY_SKIP_ARITH
+        asm volatile("" : "+v"(sum) : "v"(p));
+        return;
+#endif
         asm volatile("" : "+v"(Wp[a][u / 2]));
         const f2 wp = Wp[a][u / 2];
         sum += p * ((u & 1) ? __builtin_shufflevector(wp, wp, 1, 1) : __builtin_shufflevector(wp, wp, 0, 0));
@@ -1527,7 +1566,11 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
 #endif
         if (c >= (uint32_t)(A - 1) && c < TRIPS) {
             const uint32_t k = c - (uint32_t)(A - 1);  // this row of the band is complete
+#ifdef KC_POLY_SKIP_RING
+            if (p_ok && ring == nullptr) {
+#else
             if (p_ok) {
+#endif
                 float *o = ring + (k & 7u) * KC_POLY2_RING_PITCH + rj;
                 o[0] = acc[A - 1].x;
                 o[1] = acc[A - 1].y;
@@ -1536,9 +1579,16 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
             KC_POLY_CLOCK(tm3);
             tm4 = tm3;
 #endif
+#ifdef KC_POLY_SKIP_RING
+            if ((k & 3u) == 3u && ring == nullptr) {
+#else
             if ((k & 3u) == 3u) {
+#endif
                 KC_POLY2_BARRIER();  // both halves of the four rows are in the ring (and everybody is done with the four before)
                 const float *rows4 = ring + (k & 4u) * KC_POLY2_RING_PITCH;
+#ifdef KC_POLY_SKIP_H
+                if (rows4 == nullptr)
+#endif
                 for (uint32_t r0 = 0; r0 < 4u; r0 += rows_per_pass) {
                     const float *row = rows4 + (r0 + hr) * KC_POLY2_RING_PITCH;
                     float t = 0.0f;
@@ -1658,8 +1708,15 @@ hipError_t launch_resize_poly2(const ResizePlanes &p, int batch, uint32_t dw, ui
     const uint32_t pair_floats = (8u * KC_POLY2_RING_PITCH + 256u + tw * (h.stride | 1u) + 3u) / 4u * 4u;
     const size_t lds = std::max((size_t)2 * pair_floats * sizeof(float), resize_down_lds_bytes(16, gen_ncp, gen_tw, h.stride));
     if (lds > 64u * 1024u) return hipErrorInvalidValue;
-    static const int xcd_env = std::getenv("KC_POLY_XCD") ? std::atoi(std::getenv("KC_POLY_XCD")) : -1;
-    const XcdOrder x = xcd_order(b.n_wgx, b.n_bands, xcd_env < 0 ? xcd : xcd_env != 0);
+    static const int xcd_env = std::getenv("KC_POLY2_XCD") ? std::atoi(std::getenv("KC_POLY2_XCD")) : -1;  // 0: plain order, 1: band-major eighths, 2: strip-major
+    (void)xcd;
+    XcdOrder x{ 0, 0, 0, 0 };
+    if (xcd_env == 2) {
+        x = xcd_order(b.n_wgx, b.n_bands, true);
+    } else if (xcd_env != 0 && b.n_band_wgs >= 16u) {
+        x.per = (b.n_band_wgs + 7u) / 8u;
+        x.n = b.n_band_wgs;
+    }
     dim3 grid((x.per ? 8u * x.per : b.n_band_wgs) + nt * b.gen_gx, 1, batch);
     if (ages == 2) launch_resize_poly2_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, b, pair_floats, x);
     else if (ages == 4) launch_resize_poly2_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, b, pair_floats, x);
