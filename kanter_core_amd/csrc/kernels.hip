@@ -1011,9 +1011,6 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
     if (by >= B.nyb) {
-#ifdef KC_POLY_SKIP_GEN  // tuning builds: what the launch costs without its border tiles (their rows stay unwritten)
-        return;
-#endif
         const uint32_t t = by - B.nyb;
         resize_down_tile<4>(S, src, spitch, dst, dpitch, B.ty0[t], B.th[t], V, wave, lane);
         return;
@@ -1051,13 +1048,7 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
     auto mad = [&](f4 &sum, const f4 &p, int a, int u) {
         // (the empty statement keeps the pair where it is and the broadcast inside the loop: hoisted out of it, the 48 splats
         // would be 96 more registers -- tried: 303 VGPRs, slower)
-#ifdef KC_POLY_SKIP_ARITH  // tuning builds: the trips without their arithmetic (the rows are only touched)
-        asm volatile("" : "+v"(sum) : "v"(p));
-        return;
-#endif
-#ifndef KC_POLY_NO_ASM
         asm volatile("" : "+v"(Wp[a][u / 2]));
-#endif
         const f2 wp = Wp[a][u / 2];
         const f2 w2 = (u & 1) ? __builtin_shufflevector(wp, wp, 1, 1) : __builtin_shufflevector(wp, wp, 0, 0);
         const f2 lo = f2{ p.x, p.y } * w2, hi = f2{ p.z, p.w } * w2;
@@ -1109,11 +1100,7 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
 #endif
         if (c >= (uint32_t)(A - 1)) {
             const uint32_t k = c - (uint32_t)(A - 1);  // this row of the band is complete
-#ifdef KC_POLY_SKIP_RING
-            if (q_ok && ringq == nullptr) {
-#else
             if (q_ok) {
-#endif
                 float *o = ringq + (k & 3u) * S.row_floats;
                 o[0] = acc[A - 1].x;
                 o[1] = acc[A - 1].y;
@@ -1129,9 +1116,7 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifndef KC_POLY_SKIP_H  // tuning builds: the launch without its horizontal passes (nothing is written)
                 if (lane < S.tw) resize_down_hrows(S, ring, lane, dst + (size_t)(yf + k - 3u) * dpitch, dpitch, 4u);
-#endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #ifdef KC_POLY_TIMING
@@ -1439,9 +1424,6 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
         }
     }
     if (wg >= B.n_band_wgs) {
-#ifdef KC_POLY_SKIP_GEN
-        return;
-#endif
         // rows near the border: the general form, all four waves on one tile
         const uint32_t g = wg - B.n_band_wgs;
         const uint32_t t = g / B.gen_gx, bx = g - t * B.gen_gx;
@@ -1496,10 +1478,6 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
         for (int u = 0; u < RT; u += 2)
             Wp[a][u / 2] = f2{ V.w[(size_t)B.ya * V.stride + a * RT + u], V.w[(size_t)B.ya * V.stride + a * RT + u + 1] };
     auto mad = [&](f2 &sum, const f2 &p, int a, int u) {
-#ifdef KC_POLY_SKIP_ARITH
-        asm volatile("" : "+v"(sum) : "v"(p));
-        return;
-#endif
         asm volatile("" : "+v"(Wp[a][u / 2]));
         const f2 wp = Wp[a][u / 2];
         sum += p * ((u & 1) ? __builtin_shufflevector(wp, wp, 1, 1) : __builtin_shufflevector(wp, wp, 0, 0));
@@ -1520,22 +1498,12 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
     const float *hwt = hw + hxs * hsp;
     const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)hcount);
     const bool uniform = (nu & 3u) == 0u && __builtin_amdgcn_ballot_w64(hcount != nu) == 0ull;
-#ifdef KC_POLY_TIMING
-    unsigned long long tm_wait = 0, tm_arith = 0, tm_ring = 0, tm_h = 0, tm_begin, tm0, tm1, tm2, tm3, tm4;
-    KC_POLY_CLOCK(tm_begin);
-#endif
     for (uint32_t cb = 0; cb < TRIPS; cb += NB) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const uint32_t c = cb + b;  // (up to NB - 1 trips past the last one do nothing: leaving the loop from its middle would join
                                     // paths with different numbers of loads in flight, and the waits would be for all of them)
         f2 (&p)[RT] = pb[b];
-#ifdef KC_POLY_TIMING
-        KC_POLY_CLOCK(tm0);
-        asm volatile("" : "+v"(p[0]), "+v"(p[RT - 1]));
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 1) * RT) : "memory");
-        KC_POLY_CLOCK(tm1);
-#endif
         // age a holds row c - a of the band
         if (c >= (uint32_t)(A - 1) && c < ROWS) {
 #pragma unroll
@@ -1559,36 +1527,16 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
                 p[u] = col[(size_t)(cn * RT + u) * sp2];
             }
         }
-#ifdef KC_POLY_TIMING
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[A - 1]));
-        KC_POLY_CLOCK(tm2);
-        tm3 = tm4 = tm2;
-#endif
         if (c >= (uint32_t)(A - 1) && c < TRIPS) {
             const uint32_t k = c - (uint32_t)(A - 1);  // this row of the band is complete
-#ifdef KC_POLY_SKIP_RING
-            if (p_ok && ring == nullptr) {
-#else
             if (p_ok) {
-#endif
                 float *o = ring + (k & 7u) * KC_POLY2_RING_PITCH + rj;
                 o[0] = acc[A - 1].x;
                 o[1] = acc[A - 1].y;
             }
-#ifdef KC_POLY_TIMING
-            KC_POLY_CLOCK(tm3);
-            tm4 = tm3;
-#endif
-#ifdef KC_POLY_SKIP_RING
-            if ((k & 3u) == 3u && ring == nullptr) {
-#else
             if ((k & 3u) == 3u) {
-#endif
                 KC_POLY2_BARRIER();  // both halves of the four rows are in the ring (and everybody is done with the four before)
                 const float *rows4 = ring + (k & 4u) * KC_POLY2_RING_PITCH;
-#ifdef KC_POLY_SKIP_H
-                if (rows4 == nullptr)
-#endif
                 for (uint32_t r0 = 0; r0 < 4u; r0 += rows_per_pass) {
                     const float *row = rows4 + (r0 + hr) * KC_POLY2_RING_PITCH;
                     float t = 0.0f;
@@ -1620,35 +1568,13 @@ __global__ __launch_bounds__(256) void resize_poly2_kernel(const ResizePlanes P,
                     }
                     if (h_ok) dst[(size_t)(yf + k - 3u + r0 + hr) * dpitch + x0 + hx] = clamp01_nan_passthrough(t);
                 }
-#ifdef KC_POLY_TIMING
-                KC_POLY_CLOCK(tm4);
-#endif
             }
         }
-#ifdef KC_POLY_TIMING
-        tm_wait += tm1 - tm0;
-        tm_arith += tm2 - tm1;
-        tm_ring += tm3 - tm2;
-        tm_h += tm4 - tm3;
-#endif
 #pragma unroll
         for (int a = A - 1; a > 0; --a) acc[a] = acc[a - 1];
         acc[0] = f2{ 0.0f, 0.0f };
       }
     }
-#ifdef KC_POLY_TIMING
-    if (lane == 0) {
-        unsigned long long tm_end;
-        KC_POLY_CLOCK(tm_end);
-        atomicAdd(&kc_poly_timing[0], tm_wait);
-        atomicAdd(&kc_poly_timing[1], tm_arith);
-        atomicAdd(&kc_poly_timing[2], tm_ring);
-        atomicAdd(&kc_poly_timing[3], tm_h);
-        atomicAdd(&kc_poly_timing[4], tm_end - tm_begin);
-        atomicAdd(&kc_poly_timing[5], 1ull);
-        atomicAdd(&kc_poly_timing[6], (unsigned long long)TRIPS);
-    }
-#endif
 }
 
 template <int A>
@@ -1721,18 +1647,6 @@ hipError_t launch_resize_poly2(const ResizePlanes &p, int batch, uint32_t dw, ui
     if (ages == 2) launch_resize_poly2_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, b, pair_floats, x);
     else if (ages == 4) launch_resize_poly2_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, b, pair_floats, x);
     else launch_resize_poly2_a<6>(grid, lds, s, ratio, p, dw, dh, v, h, b, pair_floats, x);
-#ifdef KC_POLY_TIMING
-    if (std::getenv("KC_POLY_TIMING")) {
-        unsigned long long t[8] = {}, zero[8] = {};
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(kc_poly_timing), sizeof t);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(kc_poly_timing), zero, sizeof zero);
-        if (t[5])
-            std::fprintf(stderr, "poly2 timing A=%u R=%u rows=%u tw=%u: %llu band waves, %.1f trips each; clocks per wave: rows-wait %.0f, arithmetic %.0f, ring %.0f, "
-                                 "horizontal %.0f, band total %.0f\n", ages, ratio, b.rows, tw, t[5], (double)t[6] / t[5], (double)t[0] / t[5], (double)t[1] / t[5],
-                         (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5]);
-    }
-#endif
     return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,8 +109,18 @@ static float run(const float *src, float *out, const Geo &g, int reps)
     CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) tile_read<LW, RT, NB, ALU><<<grid, 64 * g.waves_per_wg>>>(src, out, g);
     CK(hipDeviceSynchronize());
+    // TILE_READ_GAP_US=n: the host waits for every launch and then n microseconds more before the next one (how a caller that
+    // does other work between resizes sees the kernel; the times printed then include the gaps -- read them from a kernel trace)
+    static const int gap_us = std::getenv("TILE_READ_GAP_US") ? std::atoi(std::getenv("TILE_READ_GAP_US")) : -1;
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) tile_read<LW, RT, NB, ALU><<<grid, 64 * g.waves_per_wg>>>(src, out, g);
+    for (int i = 0; i < reps; ++i) {
+        tile_read<LW, RT, NB, ALU><<<grid, 64 * g.waves_per_wg>>>(src, out, g);
+        if (gap_us >= 0) {
+            CK(hipDeviceSynchronize());
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < gap_us) {}
+        }
+    }
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -153,9 +164,19 @@ int main(int argc, char **argv)
     float *src, *out;
     CK(hipMalloc(&src, (size_t)size * size * 4));
     CK(hipMalloc(&out, (size_t)64 << 20));
-    CK(hipMemset(src, 0, (size_t)size * size * 4));
-    std::printf("# source %u^2 f32 (%.1f MB algorithmic); columns: lane floats, rows per trip, trips in flight, new cols per strip, rows per band (output rows at this ratio),\n"
-                "# ages, alu per row, waves per workgroup, order -> waves, workgroups, fetched MB, us, fetched TB/s, algorithmic TB/s\n", size, size * (double)size * 4 / 1e6);
+    if (argc > 2 && std::strcmp(argv[2], "zeros") == 0) {
+        CK(hipMemset(src, 0, (size_t)size * size * 4));  // (all-zero planes read measurably faster than real data: see profiles/r04_poly_weights.md)
+    } else {
+        std::vector<float> h((size_t)size * size);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (float &v : h) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            v = (float)(x >> 40) * (1.0f / 16777216.0f);
+        }
+        CK(hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    }
+    std::printf("# source %u^2 f32, %s (%.1f MB algorithmic); columns: lane floats, rows per trip, trips in flight, new cols per strip, rows per band (output rows at this ratio),\n"
+                "# ages, alu per row, waves per workgroup, order -> waves, workgroups, fetched MB, us, fetched TB/s, algorithmic TB/s\n", size, argc > 2 ? argv[2] : "random values", size * (double)size * 4 / 1e6);
     struct Case { int lw, rt, nb; uint32_t strip_new, rows, ages, alu, wpw, order, wps, mis; };
     std::vector<Case> cases;
     // the shipped geometry at ratio 8 (Gaussian: 6 ages; windows of 256 columns for 192 new ones, bands of 12 rows), loads only, by trips in flight
