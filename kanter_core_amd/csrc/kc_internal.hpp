@@ -127,7 +127,7 @@ inline XcdOrder xcd_order(uint32_t gx, uint32_t gy, bool want)
     return o;
 }
 hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,
-                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, bool xcd, hipStream_t s);
+                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, hipStream_t s);
 // The same ranges with two waves to a band's strip (8-byte lanes, a shared ring, the horizontal pass split by pixels): kernels.hip
 hipError_t launch_resize_poly2(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tw,
                                uint32_t gen_tw, uint32_t gen_ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, bool xcd,

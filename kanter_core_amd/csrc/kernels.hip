@@ -860,6 +860,36 @@ static __device__ __forceinline__ DownStrip resize_down_stage(float *lds, const 
     return S;
 }
 
+// The same for ONE wave (resize_poly_kernel's band waves, each with a strip of its own): `lds` is the wave's own area -- four
+// intermediate rows, then the taps -- filled by its 64 lanes; the caller orders it with a wave barrier.
+static __device__ __forceinline__ DownStrip resize_down_stage_wave(float *lds, const TapsDev &H, uint32_t dw, uint32_t tile_w, uint32_t bx,
+                                                                   uint32_t lane)
+{
+    DownStrip S;
+    S.x0 = bx * tile_w;
+    const uint32_t x1 = min(S.x0 + tile_w, dw);
+    S.tw = x1 - S.x0;
+    S.c0 = H.left[S.x0] & ~3u;
+    S.nq = (H.left[x1 - 1] + H.count[x1 - 1] - S.c0 + 3u) / 4u;  // <= 64 (host-checked)
+    S.row_floats = KC_DOWN_ROW_FLOATS;
+    S.hsp = H.stride | 1u;
+    S.tmp = lds;
+    S.hl = reinterpret_cast<uint32_t *>(lds + 4u * S.row_floats);
+    S.hn = S.hl + tile_w;
+    S.hw = reinterpret_cast<float *>(S.hn + tile_w);  // tile_w x hsp
+    for (uint32_t i = lane; i < S.tw; i += 64u) {
+        S.hl[i] = H.left[S.x0 + i] - S.c0;
+        S.hn[i] = H.count[S.x0 + i];
+    }
+    for (uint32_t i = lane; i < S.tw * H.stride; i += 64u) {
+        const uint32_t x = i / H.stride, j = i - x * H.stride;
+        S.hw[x * S.hsp + j] = H.w[(size_t)S.x0 * H.stride + i];
+    }
+    return S;
+}
+// floats of such an area
+static inline uint32_t resize_down_wave_floats(uint32_t tile_w, uint32_t hstride) { return (4u * KC_DOWN_ROW_FLOATS + 2u * tile_w + tile_w * (hstride | 1u) + 3u) / 4u * 4u; }
+
 // Horizontal pass of four intermediate rows (row, row + row_floats, ...) for this lane's output column.
 static __device__ __forceinline__ void resize_down_hrows(const DownStrip &S, const float *row, uint32_t lane, float *dst_row,
                                                          uint32_t dpitch, uint32_t nrows)
@@ -969,69 +999,67 @@ __global__ __launch_bounds__(256) void resize_down_kernel(const ResizePlanes P, 
 // sit in scalar registers), every source row of the band is loaded once, and after each four finished rows the wave runs the
 // horizontal pass on its ring by itself: no barrier after the tap staging.  Same taps in the same order: same roundings.
 // Rows near the border (and what does not fill a band) are tiles of the general form, run by the launch's last workgroups.
+// Which band wave sits where (round 4): the four waves of a workgroup are four NEIGHBOURING STRIPS of one band (their windows
+// share halo columns: one L1), each with its strip's taps staged in LDS by itself, and workgroup id % 8 -- the XCD -- works
+// through the k-th eighth of the bands one whole band after the other (a band and the next one share A - 1 trips of rows: one
+// L2; every XCD streams a contiguous eighth of the plane).  The bare access pattern takes 12.9 us like this against 18.8 with
+// four bands of one strip per workgroup (profiles/tile_read_bench.hip), the kernels 8 - 20 % less.
 struct PolyBands {
     uint32_t ya, yb;    // regular rows handled as bands: [ya, yb), yb - ya a multiple of 4
     uint32_t rows;      // rows per band (a multiple of 4; the last band may be shorter)
     uint32_t n_bands;
-    uint32_t nyb;       // workgroups (of 4 bands) along y; the general tiles follow
     uint32_t ty0[4], th[4];  // general tiles: first row, rows (<= 16)
-    uint32_t row_major;      // with the XCD order: an XCD's eighth of the tiles runs along the rows (whole band groups), not down the strips
+    // A workgroup's four waves are four neighbouring STRIPS of one band (each with its taps staged by itself); the grid is
+    // one-dimensional and XCD k (workgroup id % 8) works through the k-th eighth of the band workgroups band by band; the
+    // border tiles follow.  n_sq strip quads per band, n_band_wgs = n_bands * n_sq, xper = ceil(n_band_wgs / 8), gx strips,
+    // wave_floats of LDS per wave.
+    uint32_t n_sq, n_band_wgs, xper, gx, wave_floats;
 };
 
-#ifdef KC_POLY_TIMING
-#include <cstdio>
-// Tuning builds only (tools/build_variant.sh poly_timing -DKC_POLY_TIMING): where a band wave's clocks go, summed over the waves of
-// a launch: [0] waiting for a trip's rows, [1] the trip's arithmetic, [2] ring writes, [3] horizontal passes, [4] whole band,
-// [5] band waves, [6] trips.  launch_resize_poly prints and clears them when KC_POLY_TIMING is set in the environment.
-__device__ unsigned long long kc_poly_timing[8];
-#define KC_POLY_CLOCK(var) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); var = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
-#endif
 
 template <int A, int RT>
 __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, uint32_t dw, uint32_t dh, TapsDev V,
-                                                          TapsDev H, uint32_t tile_w, uint32_t ncp, PolyBands B, XcdOrder X)
+                                                          TapsDev H, uint32_t tile_w, uint32_t ncp, PolyBands B)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    uint32_t bx = blockIdx.x, by = blockIdx.y;
-    if (X.per) {  // tiles in XCD order (kc_internal.hpp)
-        const uint32_t tile = (blockIdx.x & 7u) * X.per + (blockIdx.x >> 3);
-        if (tile >= X.n) return;
-        bx = __umulhi(tile, X.magic);
-        by = tile - bx * X.gy;
-        if (B.row_major) {  // (X was made for the transposed grid: quotient = row of tiles, remainder = strip)
-            const uint32_t t = bx;
-            bx = by;
-            by = t;
-        }
-    }
-    const DownStrip S = resize_down_stage(lds, H, dw, tile_w, 16u, ncp, bx);
     const float *__restrict__ src = P.src[blockIdx.z];
     float *__restrict__ dst = P.dst[blockIdx.z];
     const uint32_t spitch = P.spitch[blockIdx.z], dpitch = P.dpitch[blockIdx.z];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
-    if (by >= B.nyb) {
-        const uint32_t t = by - B.nyb;
+    const uint32_t sp4 = spitch / 4u;
+    DownStrip S;
+    uint32_t yf;
+    f4 pn[RT];
+    const f4 *col;
+    // ---- four strips of one band per workgroup, the bands dealt to the XCDs in eighths (profiles/r04_poly_weights.md 5a: the
+    // halo columns of neighbouring strips meet in one L1, a band and the next one in one L2) ----
+    if (blockIdx.x >= 8u * B.xper) {
+        const uint32_t g = blockIdx.x - 8u * B.xper, t = g / B.gx;
+        S = resize_down_stage(lds, H, dw, tile_w, 16u, ncp, g - t * B.gx);
         resize_down_tile<4>(S, src, spitch, dst, dpitch, B.ty0[t], B.th[t], V, wave, lane);
         return;
     }
-    // The band's first rows are requested BEFORE the barrier behind the strip's horizontal taps: the taps' staging (global reads)
-    // and these loads are in flight together.  A wave without a band still takes the barrier.
-    const uint32_t bi = by * 4u + wave;
-    const bool has_band = bi < B.n_bands;
-    const uint32_t yf = B.ya + B.rows * (has_band ? bi : 0u);
+    const uint32_t tile = (blockIdx.x & 7u) * B.xper + (blockIdx.x >> 3);
+    if (tile >= B.n_band_wgs) return;
+    const uint32_t bi = tile / B.n_sq, strip = (tile - bi * B.n_sq) * 4u + wave;
+    if (strip >= B.gx) return;  // (no workgroup barrier on this path)
+    yf = B.ya + B.rows * bi;
+    // the band's first rows are requested before the taps are staged: both are in flight together
+    {
+        const uint32_t x0 = strip * tile_w, x1 = min(x0 + tile_w, dw), c0 = H.left[x0] & ~3u;
+        const uint32_t nq = (H.left[x1 - 1] + H.count[x1 - 1] - c0 + 3u) / 4u;
+        col = reinterpret_cast<const f4 *>(src + c0) + min(lane, nq - 1u) + (size_t)V.left[yf] * sp4;
+    }
+#pragma unroll
+    for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)u * sp4];
+    S = resize_down_stage_wave(lds + wave * B.wave_floats, H, dw, tile_w, strip, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t ROWS = min(B.rows, B.yb - yf);
-    const uint32_t sp4 = spitch / 4u;
     const bool q_ok = lane < S.nq;
     const uint32_t q = min(lane, S.nq - 1u);
-    const f4 *col = reinterpret_cast<const f4 *>(src + S.c0) + q + (size_t)V.left[yf] * sp4;
-    f4 pn[RT];
-    if (has_band) {
-#pragma unroll
-        for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)u * sp4];
-    }
-    __syncthreads();  // the strip's horizontal taps
-    if (!has_band) return;
     // The A RT weights, two to a VECTOR register pair (the same values in every lane); either half of a pair is broadcast to both
     // lanes of a packed multiply by op_sel, at no cost.  As scalar registers -- rounds 2 and 3 -- the compiler wanted every
     // weight as an SGPR PAIR (w, w) for v_pk_mul_f32: 96 scalar registers at ratio 8, which do not exist, so it parked them in
@@ -1054,27 +1082,16 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
         const f2 lo = f2{ p.x, p.y } * w2, hi = f2{ p.z, p.w } * w2;
         sum = f4{ sum.x + lo.x, sum.y + lo.y, sum.z + hi.x, sum.w + hi.y };
     };
-    float *ring = S.tmp + wave * 4u * S.row_floats;
+    float *ring = S.tmp;
     float *ringq = ring + 4u * q + (q >> 3);  // swizzled: a quad never straddles a multiple of 32
     f4 acc[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) acc[a] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
     const uint32_t TRIPS = ROWS + A - 1;
-#ifdef KC_POLY_TIMING
-    unsigned long long tm_wait = 0, tm_arith = 0, tm_ring = 0, tm_h = 0, tm_begin, tm0, tm1, tm2, tm3, tm4;
-    KC_POLY_CLOCK(tm_begin);
-#endif
     for (uint32_t c = 0; c < TRIPS; ++c) {
         f4 p[RT];
-#ifdef KC_POLY_TIMING
-        KC_POLY_CLOCK(tm0);
-#endif
 #pragma unroll
         for (int u = 0; u < RT; ++u) p[u] = pn[u];
-#ifdef KC_POLY_TIMING
-        asm volatile("" : "+v"(p[0]), "+v"(p[RT - 1]));
-        KC_POLY_CLOCK(tm1);
-#endif
         if (c + 1u < TRIPS) {
 #pragma unroll
             for (int u = 0; u < RT; ++u) pn[u] = col[(size_t)((c + 1u) * RT + u) * sp4];
@@ -1093,11 +1110,6 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
                     for (int u = 0; u < RT; ++u) mad(acc[a], p[u], a, u);
                 }
         }
-#ifdef KC_POLY_TIMING
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[A - 1]));
-        KC_POLY_CLOCK(tm2);
-        tm3 = tm4 = tm2;
-#endif
         if (c >= (uint32_t)(A - 1)) {
             const uint32_t k = c - (uint32_t)(A - 1);  // this row of the band is complete
             if (q_ok) {
@@ -1107,10 +1119,6 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
                 o[2] = acc[A - 1].z;
                 o[3] = acc[A - 1].w;
             }
-#ifdef KC_POLY_TIMING
-            KC_POLY_CLOCK(tm3);
-            tm4 = tm3;
-#endif
             if ((k & 3u) == 3u) {
                 // the ring is this wave's own: its lanes' writes only have to be ordered before its lanes' reads
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1119,34 +1127,12 @@ __global__ __launch_bounds__(256) void resize_poly_kernel(const ResizePlanes P, 
                 if (lane < S.tw) resize_down_hrows(S, ring, lane, dst + (size_t)(yf + k - 3u) * dpitch, dpitch, 4u);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-#ifdef KC_POLY_TIMING
-                KC_POLY_CLOCK(tm4);
-#endif
             }
         }
-#ifdef KC_POLY_TIMING
-        tm_wait += tm1 - tm0;
-        tm_arith += tm2 - tm1;
-        tm_ring += tm3 - tm2;
-        tm_h += tm4 - tm3;
-#endif
 #pragma unroll
         for (int a = A - 1; a > 0; --a) acc[a] = acc[a - 1];
         acc[0] = f4{ 0.0f, 0.0f, 0.0f, 0.0f };
     }
-#ifdef KC_POLY_TIMING
-    if (lane == 0) {
-        unsigned long long tm_end;
-        KC_POLY_CLOCK(tm_end);
-        atomicAdd(&kc_poly_timing[0], tm_wait);
-        atomicAdd(&kc_poly_timing[1], tm_arith);
-        atomicAdd(&kc_poly_timing[2], tm_ring);
-        atomicAdd(&kc_poly_timing[3], tm_h);
-        atomicAdd(&kc_poly_timing[4], tm_end - tm_begin);
-        atomicAdd(&kc_poly_timing[5], 1ull);
-        atomicAdd(&kc_poly_timing[6], (unsigned long long)TRIPS);
-    }
-#endif
 }
 
 // Fused resample + Mix chain: phase 2's four results are input slot K-1 of the chain program, the
@@ -1283,16 +1269,16 @@ hipError_t launch_resize_down(const ResizePlanes &p, int batch, uint32_t dw, uin
 
 template <int A>
 static void launch_resize_poly_a(dim3 grid, size_t lds, hipStream_t s, uint32_t rt, const ResizePlanes &p, uint32_t dw, uint32_t dh,
-                                 TapsDev v, TapsDev h, uint32_t tile_w, uint32_t ncp, const PolyBands &b, const XcdOrder &x)
+                                 TapsDev v, TapsDev h, uint32_t tile_w, uint32_t ncp, const PolyBands &b)
 {
-    if (rt == 2) resize_poly_kernel<A, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b, x);
-    else if (rt == 4) resize_poly_kernel<A, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b, x);
-    else resize_poly_kernel<A, 8><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b, x);
+    if (rt == 2) resize_poly_kernel<A, 2><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
+    else if (rt == 4) resize_poly_kernel<A, 4><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
+    else resize_poly_kernel<A, 8><<<grid, 256, lds, s>>>(p, dw, dh, v, h, tile_w, ncp, b);
 }
 
 // Rows [reg_a, reg_b) of the vertical table are regular: `ages` x `ratio` taps each, windows `ratio` apart, equal weights.
 hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uint32_t dh, TapsDev v, TapsDev h, uint32_t tile_w,
-                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, bool xcd, hipStream_t s)
+                              uint32_t ncp, uint32_t reg_a, uint32_t reg_b, uint32_t ages, uint32_t ratio, hipStream_t s)
 {
     if (dw == 0 || dh == 0) return hipSuccess;
     if (batch < 1 || batch > 4) return hipErrorInvalidValue;
@@ -1306,24 +1292,23 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     // of their neighbours' windows, taller ones leave too few waves to overlap one wave's arithmetic with another's loads
     // (bands sized for one wave per SIMD, 20+ rows, were slower still); with four planes per launch the waves are there and
     // 12 / 24 / 36 / 48 rows give 80.5 / 71.2 / 74.8 / 85.4 us.
-    // A launch whose waves are all resident at once lasts as long as ONE wave lives -- A - 1 + rows trips of ~470 vector
-    // instructions each (SQ counters: 13 us of issue + 10 us of waits per wave at ratio 8, profiles/r04_poly_weights.md) -- so
-    // images that do not fill the chip take SHORT bands: 2048^2 -> 512^2 19.3 / 15.3 / 11.5 us with 12 / 8 / 4 rows,
-    // 2048^2 -> 256^2 26.6 / 20.3 / 16.5, 1024^2 -> 256^2 16.7 / 13.2 / 9.6 (profiles/r04_poly_rows_small.txt); past about one
-    // wave per SIMD the windows short bands re-read cost more than their trips save (4096^2 -> 1024^2: 22.2 / 24.7 / 33.5 us).
+    // A launch whose waves are all resident at once lasts as long as ONE wave lives -- A - 1 + rows trips -- so images that do
+    // not fill the chip take SHORT bands: 2048^2 -> 512^2 19.3 / 15.3 / 11.5 us with 12 / 8 / 4 rows, 2048^2 -> 256^2
+    // 26.6 / 20.3 / 16.5, 1024^2 -> 256^2 16.7 / 13.2 / 9.6 (profiles/r04_poly_rows_small.txt); past about one wave per SIMD the
+    // windows short bands re-read cost more than their trips save (4096^2 -> 1024^2: 22.2 / 24.7 / 33.5 us).
     static const uint32_t rows_env = std::getenv("KC_POLY_ROWS") ? std::max(4u, (uint32_t)std::atoi(std::getenv("KC_POLY_ROWS")) / 4u * 4u) : 0u;
     b.rows = (batch >= 2 && ages >= 4) ? 24u : 12u;
+    b.gx = (dw + tile_w - 1) / tile_w;
     {
-        const uint64_t strips = (dw + tile_w - 1) / tile_w, regular = (reg_b - reg_a) / 4u * 4u;
+        const uint64_t regular = (reg_b - reg_a) / 4u * 4u;
         for (uint32_t r : { 4u, 8u })
-            if (strips * ((regular + r - 1) / r) * (uint64_t)batch <= 1100u) {
+            if (b.gx * ((regular + r - 1) / r) * (uint64_t)batch <= 1100u) {
                 b.rows = r;
                 break;
             }
     }
     if (rows_env) b.rows = rows_env;
     b.n_bands = (b.yb - b.ya + b.rows - 1) / b.rows;
-    b.nyb = (b.n_bands + 3u) / 4u;
     // what is left: rows above the first band and below the last one, as general tiles of at most 16 rows
     uint32_t nt = 0;
     auto add_tiles = [&](uint32_t y0, uint32_t y1) {
@@ -1336,29 +1321,19 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
         return true;
     };
     if (!add_tiles(0, b.ya) || !add_tiles(b.yb, dh)) return hipErrorInvalidValue;
-    const size_t lds = resize_down_lds_bytes(16, ncp, tile_w, h.stride);
-    dim3 grid((dw + tile_w - 1) / tile_w, b.nyb + nt, batch);
-    // KC_POLY_XCD=0 / 1: never / always (A/B); default: the caller's hint (planes that fit the Infinity Cache)
-    // KC_POLY_XCD=2: the eighths along the rows (whole band groups per XCD), as resize_poly2_kernel has them
-    static const int xcd_env = std::getenv("KC_POLY_XCD") ? std::atoi(std::getenv("KC_POLY_XCD")) : -1;
-    b.row_major = xcd_env == 2 ? 1u : 0u;
-    const XcdOrder x = b.row_major ? xcd_order(grid.y, grid.x, true) : xcd_order(grid.x, grid.y, xcd_env < 0 ? xcd : xcd_env != 0);
-    if (x.per) grid = dim3(8u * x.per, 1, batch);
-    if (ages == 2) launch_resize_poly_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
-    else if (ages == 4) launch_resize_poly_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
-    else launch_resize_poly_a<6>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b, x);
-#ifdef KC_POLY_TIMING
-    if (std::getenv("KC_POLY_TIMING")) {
-        unsigned long long t[8] = {}, zero[8] = {};
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(kc_poly_timing), sizeof t);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(kc_poly_timing), zero, sizeof zero);
-        if (t[5])
-            std::fprintf(stderr, "poly timing A=%u R=%u rows=%u: %llu band waves, %.1f trips each; clocks per wave: rows-wait %.0f, arithmetic %.0f, ring %.0f, "
-                                 "horizontal %.0f, band total %.0f\n", ages, ratio, b.rows, t[5], (double)t[6] / t[5], (double)t[0] / t[5], (double)t[1] / t[5],
-                         (double)t[2] / t[5], (double)t[3] / t[5], (double)t[4] / t[5]);
-    }
-#endif
+    // Band workgroups: four neighbouring strips of one band each, dealt to the XCDs in eighths of the band-major sequence (what
+    // this order is worth, same run, us: Gaussian 4096^2 -> 512^2 30.6 -> 25.2, Lanczos3 -> 1024^2 24.7 -> 22.4, Triangle -> 512^2
+    // 18.1 -> 16.0, 8192^2 -> 1024^2 83.9 -> 67.8; RGBA Triangle 57.1 -> 48.5 = 0.70 of the HBM peak: profiles/r04_poly_by_band.txt)
+    b.n_sq = (b.gx + 3u) / 4u;
+    b.n_band_wgs = b.n_bands * b.n_sq;
+    b.xper = (b.n_band_wgs + 7u) / 8u;
+    b.wave_floats = resize_down_wave_floats(tile_w, h.stride);
+    const size_t lds = std::max(resize_down_lds_bytes(16, ncp, tile_w, h.stride), (size_t)4 * b.wave_floats * sizeof(float));
+    if (lds > 64u * 1024u) return hipErrorInvalidValue;
+    const dim3 grid(8u * b.xper + nt * b.gx, 1, batch);
+    if (ages == 2) launch_resize_poly_a<2>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
+    else if (ages == 4) launch_resize_poly_a<4>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
+    else launch_resize_poly_a<6>(grid, lds, s, ratio, p, dw, dh, v, h, tile_w, ncp, b);
     return hipGetLastError();
 }
 

@@ -662,10 +662,7 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 return KC_OK;
             }
             hipError_t e = t.poly ? launch_resize_poly(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.ncp, tv->host.reg_a,
-                                                       tv->host.reg_b, tv->host.reg_ages, tv->host.reg_ratio,
-                                                       // (windows of up to 24 rows: Lanczos3 4:1 23.9 -> 22.3 us, Triangle 8:1 17.2 ->
-                                                       // 16.1; Gaussian 8:1, 48 rows, 30.8 -> 35.1 -- profiles/r03_poly_xcd_ab.txt)
-                                                       fits_cache && tv->host.reg_ages * tv->host.reg_ratio <= 24, c.stream)
+                                                       tv->host.reg_b, tv->host.reg_ages, tv->host.reg_ratio, c.stream)
                            : t.down ? launch_resize_down(rp, n, size.width, size.height, tv->dev, th->dev, t.tile_w, t.tile_h, t.ncp, c.stream)
                                   : launch_resize_lds(rp, n, size.width, size.height, tv->dev, th->dev, th->host.min_count, t.tile_w,
                                                       t.tile_h, t.ncp, c.stream);
