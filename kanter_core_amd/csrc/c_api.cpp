@@ -84,6 +84,7 @@ try {
     if (const char *wd = std::getenv("KC_WIDE")) c.wide = std::atoi(wd) != 0;
     if (const char *d2 = std::getenv("KC_DOWN2")) c.down2 = std::max(0, std::min(2, std::atoi(d2)));
     if (const char *p2 = std::getenv("KC_POLY2")) c.poly2 = std::atoi(p2) != 0;
+    if (const char *br = std::getenv("KC_DOWN2_BY_ROWS")) c.down2_by_rows = std::max(-1, std::min(1, std::atoi(br)));
     if (const char *p2r = std::getenv("KC_POLY2_MIN_RATIO")) c.poly2_min_ratio = std::max(2, std::atoi(p2r));
     if (const char *rt = std::getenv("KC_RESIZE_TILE_H")) c.resize_tile_h = std::atoi(rt);
     if (const char *rw = std::getenv("KC_RESIZE_TILE_W")) c.resize_tile_w = std::atoi(rw);
@@ -241,6 +242,7 @@ try {
     else if (std::strcmp(name, "join") == 0) ctx().join = value != 0;
     else if (std::strcmp(name, "wide") == 0) ctx().wide = value != 0;
     else if (std::strcmp(name, "down2") == 0 && value >= 0 && value <= 2) ctx().down2 = value;
+    else if (std::strcmp(name, "down2_by_rows") == 0 && value >= -1 && value <= 1) ctx().down2_by_rows = value;
     else if (std::strcmp(name, "poly2") == 0 && value >= 0 && value <= 1) ctx().poly2 = value;
     else if (std::strcmp(name, "poly2_min_ratio") == 0 && value >= 2) ctx().poly2_min_ratio = value;
     else if (std::strcmp(name, "cache_budget_mb") == 0 && value >= 0) ctx().cache_budget_mb = value;
@@ -262,6 +264,7 @@ try {
     else if (std::strcmp(name, "join") == 0) *value = ctx().join ? 1 : 0;
     else if (std::strcmp(name, "wide") == 0) *value = ctx().wide ? 1 : 0;
     else if (std::strcmp(name, "down2") == 0) *value = ctx().down2;
+    else if (std::strcmp(name, "down2_by_rows") == 0) *value = ctx().down2_by_rows;
     else if (std::strcmp(name, "poly2") == 0) *value = ctx().poly2;
     else if (std::strcmp(name, "poly2_min_ratio") == 0) *value = ctx().poly2_min_ratio;
     else if (std::strcmp(name, "cache_budget_mb") == 0) *value = ctx().cache_budget_mb;

@@ -56,13 +56,21 @@ __global__ __launch_bounds__(256) void resize_down2_kernel(const ResizePlanes P,
     // share 9 of their ~30 source rows.  With xcd_per set the grid is one-dimensional and XCD k works through the k-th
     // eighth of the tiles in strip-major order, so that the rows two neighbours share are fetched into one L2, once.
     uint32_t bx = blockIdx.x, by = blockIdx.y;
+    uint32_t g;  // row group: output rows 4 g .. 4 g + 3
+    if (A.by_rows) {
+        const uint32_t tile = (blockIdx.x & 7u) * A.xcd_per + (blockIdx.x >> 3);
+        const uint32_t job = tile * 4u + wave;
+        if (job >= A.n_tiles) return;  // (n_tiles: jobs here; no barrier anywhere in this kernel)
+        g = __umulhi(job, A.gy_magic);  // job / strips
+        bx = job - g * A.gy;
+    } else
     if (A.xcd_per) {
         const uint32_t tile = (blockIdx.x & 7u) * A.xcd_per + (blockIdx.x >> 3);
         if (tile >= A.n_tiles) return;
         bx = __umulhi(tile, A.gy_magic);  // tile / gy (host-checked to be exact for every tile)
         by = tile - bx * A.gy;
     }
-    const uint32_t g = by * 4u + wave;  // row group: output rows 4 g .. 4 g + 3
+    if (!A.by_rows) g = by * 4u + wave;
     if (4u * g >= A.dh) return;         // (no barrier anywhere in this kernel)
     const uint32_t x0 = bx * A.tile_w, x1 = min(x0 + A.tile_w, A.dw);
     // the strip's first source column (a multiple of 4) and its width in quads (<= 64), and the group's first record: two
@@ -251,12 +259,31 @@ hipError_t launch_resize_down2(const ResizePlanes &p, int batch, const Down2Args
     if (a.tile_w > 64u * hc) return hipErrorInvalidValue;
     dim3 grid((a.dw + a.tile_w - 1) / a.tile_w, (a.dh + 15u) / 16u, batch);
     Down2Args a2 = a;
+    a2.by_rows = 0;
     // KC_DOWN2_XCD=0 / 1: never / always (A/B); default: when the planes fit the Infinity Cache (a.xcd_per as the caller's hint).
     // Measured (profiles/r03_down2_xcd.txt): one 4096^2 plane 27.9 -> 26.2 us, 3000^2 -> 700^2 17.9 -> 15.4; four 4096^2 planes
     // (268 MB of source, past the cache) 114.6 -> 122.7: there the plain order, whole rows at a time, is kinder to HBM.
     static const int xcd_env = std::getenv("KC_DOWN2_XCD") ? std::atoi(std::getenv("KC_DOWN2_XCD")) : -1;
     const bool xcd = xcd_env < 0 ? a.xcd_per != 0 : xcd_env != 0;
     a2.xcd_per = 0;
+    // Four strips of one row group per workgroup and the jobs dealt to the XCDs in eighths row by row (what resize_poly_kernel
+    // gained 8 - 20 % from): here it pays where the row groups' windows span several chunks (ratios from about 1.6: CatmullRom
+    // 4096^2 -> 1365^2 21.3 -> 19.3 us, RGBA 74.3 -> 63.9; Gaussian 3000^2 -> 700^2 14.6 -> 12.5, RGBA 52.4 -> 41.4; Lanczos3 2:1
+    // 24.8 -> 23.4) and costs 5 - 10 % on RGBA launches of single-chunk ratios (4096^2 -> 3000^2 111.5 -> 122.4), which keep the
+    // order above (profiles/r04_down2_by_rows.txt).
+    if (a.by_rows && grid.x >= 2) {  // (the caller's choice: resize.cpp, kc_set_option("down2_by_rows"); one strip: nothing to order,
+                                     // and the reciprocal of 1 does not fit 32 bits)
+        const uint32_t gx = grid.x, groups = (a.dh + 3u) / 4u;
+        const uint64_t jobs = (uint64_t)gx * groups, magic = ((1ull << 32) + gx - 1) / gx;
+        if (jobs < (1u << 24) && jobs * (magic * gx - (1ull << 32)) < (1ull << 32)) {
+            a2.by_rows = 1u;
+            a2.n_tiles = (uint32_t)jobs;
+            a2.gy = gx;
+            a2.gy_magic = (uint32_t)magic;
+            a2.xcd_per = (uint32_t)(((jobs + 3u) / 4u + 7u) / 8u);
+            grid = dim3(8u * a2.xcd_per, 1, batch);
+        }
+    } else
     if (xcd && grid.y >= 2) {
         const uint64_t n = (uint64_t)grid.x * grid.y, magic = ((1ull << 32) + grid.y - 1) / grid.y;
         // tile / gy == (tile * magic) >> 32 for every tile < n when n * (magic * gy - 2^32) < 2^32

@@ -99,6 +99,9 @@ struct Down2Args {
     // XCD-aware tile order (down2.hip).  The caller sets xcd_per != 0 to ask for it; the launcher fills in the rest (or clears
     // xcd_per: plain 2-D grid).
     uint32_t xcd_per, n_tiles, gy, gy_magic;
+    // by_rows != 0: a workgroup's four waves are four neighbouring STRIPS of one row group and XCD k works through the k-th eighth
+    // of the jobs row by row (xcd_per workgroups each; gy / gy_magic then divide by the number of strips): see resize_poly_kernel
+    uint32_t by_rows;
 };
 // output columns per lane of the horizontal pass: its weights live in registers (at most 9 quads per lane)
 inline uint32_t down2_cols_per_lane(uint32_t weight_quads) { return weight_quads <= 3 ? 3u : weight_quads == 4 ? 2u : 1u; }

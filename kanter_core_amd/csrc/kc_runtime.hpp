@@ -225,6 +225,8 @@ struct Context {
     bool fusion = true;
     bool replay = true;  // an evaluation that repeats the recorded one is replayed without the walk (kc_set_option("replay", 0); env KC_REPLAY)
     int down2 = 1;       // resize_down2_kernel: 0 off, 1 except where resize_poly_kernel runs at ratio 4 or 8, 2 there too (kc_set_option("down2"); env KC_DOWN2)
+    int down2_by_rows = -1;   // resize_down2_kernel's job order: four strips of one row group per workgroup, XCDs in eighths row by row;
+                              // -1: where the row groups' windows span several chunks (kc_set_option("down2_by_rows"); env KC_DOWN2_BY_ROWS)
     int poly2 = 1;            // integer-ratio down-sampling through resize_poly2_kernel (kc_set_option("poly2"); env KC_POLY2); 0: resize_poly_kernel / down2 as before
     int poly2_min_ratio = 8;  // ... from this vertical ratio on (kc_set_option("poly2_min_ratio"); env KC_POLY2_MIN_RATIO): where it measures faster
     bool plain_chains = false;  // set during a graph's first evaluation: chains as the interpreter runs them (4 planes, no joins)

@@ -654,6 +654,7 @@ static int resize_run_taps(kc_plane *const *srcs, kc_plane *const *dsts, int n, 
                 a.dw = size.width;
                 a.dh = size.height;
                 a.xcd_per = fits_cache ? 1u : 0u;
+                a.by_rows = c.down2_by_rows < 0 ? (tv->host.d2_nc > 1 ? 1u : 0u) : (c.down2_by_rows ? 1u : 0u);
                 hipError_t e2 = launch_resize_down2(rp, n, a, c.stream);
                 if (e2 != hipSuccess) return hip_fail(e2, "launch_resize_down2");
                 c.launches++;

@@ -23,6 +23,7 @@ CASES = [
     ("CatmullRom", (1030, 70), (515, 35)),      # ratio 2: 8-9 taps
     ("Triangle", (1030, 70), (515, 35)),        # ratio 2: 4 taps, one weight quad per column
     ("Lanczos3", (300, 200), (290, 193)),       # ratio 1.03: 8 taps, windows of neighbouring rows almost coincide
+    ("Gaussian", (200, 260), (48, 60)),         # ratio 4.2 on ONE strip, several chunks: the row-by-row job order has nothing to order
 ]
 
 
@@ -71,20 +72,24 @@ def test_down2_equals_oracle_and_the_kernels_it_replaces(kc, orc, filt, src, dst
     want = orc.resize_plane(p, dw, dh, filt)
     got = {}
     try:
-        for mode in (0, 1, 2):
-            kc.set_option("down2", mode)
+        for mode in (0, 1, 2, 3):
+            # 3: mode 2 with the other job order (four strips of one row group per workgroup; by default only where the
+            # windows span several chunks)
+            kc.set_option("down2", min(mode, 2))
+            kc.set_option("down2_by_rows", -1 if mode < 3 else (0 if kc.resize_down2_plan(sh, dh, kc.ResizeFilter.parse(filt))["nc"] > 1 else 1))
             n0 = kc.stats_counter("down2_launches")
             got[mode] = resize(kc, p, (dw, dh), filt)
             used = kc.stats_counter("down2_launches") - n0
             if mode == 0:
                 assert used == 0
-            if mode == 2:
+            if mode >= 2:
                 f = kc.ResizeFilter.parse(filt)
                 assert kc.resize_down2_plan(sh, dh, f)["nc"] and kc.resize_down2_plan(sw, dw, f)["tile_w"], "case does not fit the kernel"
                 assert used == 1, "%s %s->%s should reach resize_down2_kernel" % (filt, src, dst)
     finally:
         kc.set_option("down2", 1)
-    for mode in (0, 1, 2):
+        kc.set_option("down2_by_rows", -1)
+    for mode in (0, 1, 2, 3):
         assert bit_equal(got[mode], want), "%s %s->%s %s down2=%d max ulp %s" % (filt, src, dst, kind, mode, max_ulp(got[mode], want))
     if kind in ("nonfinite", "overflow"):
         assert (~np.isfinite(want)).sum() + (want == 0).sum() + (want == 1).sum() > 0
