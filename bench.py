@@ -559,8 +559,10 @@ def main():
             return n * reps / (time.perf_counter() - t0) / 1e9
 
         run(True, True)
-        return {"h2d_GBps": round(run(True, False), 1), "d2h_GBps": round(run(False, True), 1),
-                "duplex_GBps_per_direction": round(run(True, True), 1), "how": "%d MB pinned copies (the size of one RGBA8 4096^2 image), %d in a row per direction" % (mb, reps)}
+        best = lambda up, down: max(run(up, down) for _ in range(3))  # the peak is what the link CAN do: the best of three runs
+        return {"h2d_GBps": round(best(True, False), 1), "d2h_GBps": round(best(False, True), 1),
+                "duplex_GBps_per_direction": round(best(True, True), 1),
+                "how": "%d MB pinned copies (the size of one RGBA8 4096^2 image), %d in a row per direction, best of 3 runs" % (mb, reps)}
 
     main_step = step
     if args.cold:
