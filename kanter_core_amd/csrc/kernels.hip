@@ -356,7 +356,9 @@ hipError_t launch_fill(float *dst, uint32_t pitch_floats, uint32_t w, uint32_t h
     const uint64_t total = (uint64_t)row_units * h;
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    // (a 64 MiB plane: 13.0 / 12.0 / 11.2 us with 1024 / 4096 / 16384 workgroups -- profiles/r04_write_bench.txt; 11.2 us = 6.0 TB/s
+    // is what the memory system takes as writes from any kernel shape tried there)
+    if (blocks > 16384) blocks = 16384;
     fill_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(reinterpret_cast<float4 *>(dst), pitch_floats / 4, row_units, h,
                                                         v);
     return hipGetLastError();
