@@ -1589,6 +1589,10 @@ hipError_t launch_resize_poly2(const ResizePlanes &p, int batch, uint32_t dw, ui
                        waves8 = 4u * b.n_wgx * ((regular + 7u) / 8u) * (uint64_t)batch;
         if (waves4 <= 1100u) b.rows = 4u;
         else if (waves8 <= 2200u) b.rows = 8u;
+        // (and where 12-row bands give six waves per SIMD or more -- RGBA launches from 4096^2 on -- taller bands re-read less:
+        // 4096^2 -> 512^2 RGBA 68.0 -> 66.0 us, 8192^2 -> 1024^2 RGBA 286.6 -> 271.1; 2048^2 -> 256^2 RGBA 24.9 -> 38.2, one plane
+        // at 4096^2 25.3 -> 30.3: profiles/r04_poly2_rows_rgba.txt, r04_poly2_sweep.txt)
+        else if (4u * b.n_wgx * ((regular + 11u) / 12u) * (uint64_t)batch >= 6000u) b.rows = 24u;
     }
     if (rows_env) b.rows = rows_env;
     b.n_bands = (b.yb - b.ya + b.rows - 1) / b.rows;
