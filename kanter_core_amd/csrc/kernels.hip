@@ -1299,15 +1299,22 @@ hipError_t launch_resize_poly(const ResizePlanes &p, int batch, uint32_t dw, uin
     // 26.6 / 20.3 / 16.5, 1024^2 -> 256^2 16.7 / 13.2 / 9.6 (profiles/r04_poly_rows_small.txt); past about one wave per SIMD the
     // windows short bands re-read cost more than their trips save (4096^2 -> 1024^2: 22.2 / 24.7 / 33.5 us).
     static const uint32_t rows_env = std::getenv("KC_POLY_ROWS") ? std::max(4u, (uint32_t)std::atoi(std::getenv("KC_POLY_ROWS")) / 4u * 4u) : 0u;
-    b.rows = (batch >= 2 && ages >= 4) ? 24u : 12u;
+    // With four strips of a band per workgroup (round 4), same run, one plane, 8 / 12 / 16 / 24 rows: Lanczos3 4096^2 -> 1024^2
+    // 23.5 / 22.4 / 26.1 / 29.2 us; RGBA launches 12 / 16 / 24 / 32 rows: Lanczos3 4:1 68.1 / 65.8 / 70.8 / 63.5, CatmullRom 4:1
+    // 57.3 / 62.7 / 55.7 / 54.2, but 2048^2 -> 512^2 RGBA 26.4 / 26.3 / 34.2 / 34.4 (profiles/r04_poly_rows_by_band.txt): tall bands
+    // only where 12-row bands already give six waves per SIMD.
+    b.rows = 12u;
     b.gx = (dw + tile_w - 1) / tile_w;
     {
         const uint64_t regular = (reg_b - reg_a) / 4u * 4u;
+        bool small = false;
         for (uint32_t r : { 4u, 8u })
             if (b.gx * ((regular + r - 1) / r) * (uint64_t)batch <= 1100u) {
                 b.rows = r;
+                small = true;
                 break;
             }
+        if (!small && b.gx * ((regular + 11u) / 12u) * (uint64_t)batch >= 6000u) b.rows = 32u;
     }
     if (rows_env) b.rows = rows_env;
     b.n_bands = (b.yb - b.ya + b.rows - 1) / b.rows;
