@@ -152,6 +152,11 @@ KC_API int kc_get_cache_policy(void);
  *   interpreter's 4 while such a kernel is not there); 0: 4, as before.  Bit-identical either way.
  *   "down2" 0 / 1 (default) / 2: down-sampling with more than 8 taps on both axes runs resize_down2_kernel never / except
  *   where the integer-ratio streaming kernel runs at ratio 4 or 8 / wherever its tables exist (bit-identical; A/B and tests).
+ *   "down2_by_rows" -1 (default) / 0 / 1: resize_down2_kernel's job order -- four strips of one row group per workgroup and the
+ *   XCDs' eighths row by row (1), four row groups of one strip (0), or by the table (-1: 1 where the windows span several chunks).
+ *   "poly2" 1 (default) / 0, "poly2_min_ratio" 8 (default; 2, 4): down-sampling with an integer vertical ratio of at least
+ *   poly2_min_ratio and windows of 4 or 6 ages runs resize_poly2_kernel (two waves per band strip) / the kernels it replaces
+ *   (bit-identical; A/B and tests).
  *   "link_gbps" (153), "hbm_gbps" (6100): the rates kc_live_graph_partition prices a transfer / a streaming kernel with.
  *   "cache_budget_mb" (208, env KC_CACHE_BUDGET_MB): how much of a launch's streams the cache policy leaves cacheable -- 13/16 of
  *   the MI355X's 256 MB Infinity Cache; HIP reports no size for that cache, so another part sets this. */
