@@ -148,17 +148,18 @@ constexpr uint32_t KC_UPSAMPLE_ROWS = 4;
 inline uint32_t upsample_tile_rows(const UpsampleArgs &u) { return KC_UPSAMPLE_ROWS * (1024u / u.tile_w); }
 inline size_t upsample_lds_bytes(const UpsampleArgs &u)
 {
-    return ((size_t)upsample_tile_rows(u) * u.ncp + (size_t)((u.H.ratio >> 2) + u.H.qb_lo + u.H.qb_hi) * 4u * u.H.taps) * sizeof(float);
+    return ((size_t)upsample_tile_rows(u) * u.ncp + (size_t)(std::max(u.H.ratio >> 2, 1u) + u.H.qb_lo + u.H.qb_hi) * 4u * u.H.taps) * sizeof(float);
 }
 inline bool upsample_args_ok(const UpsampleArgs &u, int batch)
 {
     if (batch < 1 || batch > 4) return false;
     if (u.tile_w % 4 != 0 || u.tile_w == 0 || u.tile_w > 1024 || 256u % (u.tile_w / 4) != 0) return false;
     const uint32_t tile_h = upsample_tile_rows(u);
-    if (u.chunk == 0 || tile_h % u.chunk != 0 || u.V.ratio % u.chunk != 0 || u.H.ratio % 4 != 0) return false;
+    if (u.chunk == 0 || tile_h % u.chunk != 0 || u.V.ratio % u.chunk != 0) return false;
+    if (u.H.ratio % 4 != 0 && !(u.H.ratio == 2 && u.H.n_out % 4 == 0)) return false;
     if (u.H.taps != u.V.taps || u.ncp % 4 != 0 || !u.H.qcls || !u.V.cls) return false;
     if (u.H.n_out > 65535 || u.V.n_out > 65535) return false;  // up_div
-    if (u.ncp / 4 > 257 || ((u.H.ratio >> 2) + u.H.qb_lo + u.H.qb_hi) * u.H.taps > 256) return false;
+    if (u.ncp / 4 > 257 || (std::max(u.H.ratio >> 2, 1u) + u.H.qb_lo + u.H.qb_hi) * u.H.taps > 256) return false;
     return upsample_lds_bytes(u) <= 64 * 1024;
 }
 inline dim3 upsample_grid(const UpsampleArgs &u, int batch)

@@ -91,13 +91,15 @@ static void up_axis_build(uint32_t in_n, uint32_t out_n, TapsHost &t)
     t.up_rows.insert(t.up_rows.end(), rows.begin() + (size_t)hi_start * T, rows.end());
     // quad classes (R % 4 == 0: the four columns of a quad share their window): tap-major blocks of 4 weights
     t.up_qrows.clear();
-    if (R % 4 == 0) {
+    if (R % 4 == 0 || (R == 2 && out_n % 4 == 0 && in_n >= 8)) {
+        // (R == 2: a quad's columns 0, 1 and 2, 3 have windows one sample apart; every row sits in its own column's frame, and the
+        // one interior class is the quad at `ref`: phases 0, 1, 0, 1)
         const uint32_t nqx = out_n / 4, qb_lo = (b_lo + 3) / 4, qb_hi = (b_hi + 3) / 4;
         auto block = [&](uint32_t o0) {
             for (uint32_t j = 0; j < T; ++j)
                 for (uint32_t e = 0; e < 4; ++e) t.up_qrows.push_back(rows[(size_t)(o0 + e) * T + j]);
         };
-        for (uint32_t c = 0; c < R / 4; ++c) block(ref + 4 * c);
+        for (uint32_t c = 0; c < std::max(R / 4, 1u); ++c) block(ref + 4 * c);
         for (uint32_t q = 0; q < qb_lo; ++q) block(4 * q);
         for (uint32_t q = nqx - qb_hi; q < nqx; ++q) block(4 * q);
         t.up.qb_lo = qb_lo;
@@ -552,7 +554,8 @@ static bool up_plan(const TapsEntry &tv, const TapsEntry &th, UpsampleArgs &u)
     if (c.resize_mode >= 3 || !tv.host.up_ok || !th.host.up_ok) return false;
     u.H = th.host.up;
     u.V = tv.host.up;
-    if (u.H.taps != u.V.taps || u.H.ratio % 4 != 0 || !u.H.qcls || !u.V.cls) return false;
+    if (u.H.taps != u.V.taps || !u.H.qcls || !u.V.cls) return false;
+    if (u.H.ratio % 4 != 0 && !(u.H.ratio == 2 && u.H.n_out % 4 == 0)) return false;  // (ratio 2: "half quads", upsample.h)
     const uint32_t dw = u.H.n_out, R = u.H.ratio, T = u.H.taps;
     // widest tile that wastes the fewest threads on columns past the image (narrower tiles are taller: a thread always
     // owns 4 columns x KC_UPSAMPLE_ROWS rows)
@@ -575,7 +578,7 @@ static bool up_plan(const TapsEntry &tv, const TapsEntry &th, UpsampleArgs &u)
         quads = std::max(quads, (uint32_t)((last >> 2) - cq0) + 1u);
     }
     u.ncp = 4u * (quads | 1u);  // an odd quad count staggers consecutive rows over the LDS banks
-    if (quads > 256 || ((R >> 2) + u.H.qb_lo + u.H.qb_hi) * T > 256) return false;  // one vertical item / one class quad per thread
+    if (quads > 256 || (std::max(R >> 2, 1u) + u.H.qb_lo + u.H.qb_hi) * T > 256) return false;  // one vertical item / one class quad per thread
     u.chunk = 1;  // the most rows that share a window and divide the tile's rows (a multiple of KC_UPSAMPLE_ROWS)
     for (uint32_t d : { 8u, 4u, 2u })
         if (u.V.ratio % d == 0 && KC_UPSAMPLE_ROWS % d == 0) {

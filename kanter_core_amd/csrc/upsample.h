@@ -17,7 +17,8 @@
 // sequence unchanged (a sum that starts at +0.0 is never -0.0) -- so all threads run the same straight code.
 // With R a multiple of 4 the 4 output columns a thread owns share one window; their weights are then kept as
 // "quad classes": R / 4 + qb_lo + qb_hi blocks of taps x 4 floats, tap-major, so that one 16-byte read yields tap j's
-// weights for all four columns.
+// weights for all four columns.  R = 2 ("half quads", out a multiple of 4): columns 0, 1 of a quad share the window u and
+// columns 2, 3 the window u + 1; there is ONE interior quad class (phases 0, 1, 0, 1), every block in its columns' own frames.
 struct UpAxis {
     unsigned int n_in, n_out;
     unsigned int ratio;  // R = n_out / n_in (< 65536)
@@ -25,9 +26,9 @@ struct UpAxis {
     unsigned int taps;   // window length away from the border (odd)
     int off;             // S: window of output o starts at (int)(o / ratio) - off
     unsigned int b_lo, b_hi;  // outputs with rows of their own at either end
-    unsigned int qb_lo, qb_hi;  // the same in column quads (R % 4 == 0 only): ceil(b / 4)
+    unsigned int qb_lo, qb_hi;  // the same in column quads (R % 4 == 0 or R == 2 only): ceil(b / 4)
     const float *cls;    // class rows (HBM): ratio + b_lo + b_hi rows of `taps` floats
-    const float *qcls;   // quad classes (HBM; R % 4 == 0 only): ratio / 4 + qb_lo + qb_hi blocks of taps x 4 floats
+    const float *qcls;   // quad classes (HBM; R % 4 == 0 or R == 2 only): max(ratio / 4, 1) + qb_lo + qb_hi blocks of taps x 4 floats
 };
 
 struct UpsampleArgs {

@@ -49,13 +49,19 @@ def nasty(p):
     ((3, 3), (48, 6)),
     ((300, 7), (1200, 448)),     # 64x down the rows: chunks of 8 inside one window
     ((5, 5), (20, 40)),
+    ((64, 40), (128, 80)),       # 2x both ways: "half quads" (columns 0, 1 and 2, 3 of a thread have windows one sample apart)
+    ((130, 50), (260, 200)),     # 2x across, 4x down
+    ((1100, 16), (2200, 32)),    # 2x: three 1024-wide tiles
+    ((10, 10), (20, 20)),        # 2x, the smallest sizes the half quads take
+    ((7, 9), (14, 18)),          # 2x with a width that is not a multiple of 4: the general kernels
 ])
 def test_plain_upsample_bit_exact(kc, orc, filt, src, dst):
     (sw, sh), (dw, dh) = src, dst
     f = kc.ResizeFilter.parse(filt)
     p = nasty(splitmix_plane(SEED_A, 0, sh, sw))
     ph, pv = kc.resize_upsample_plan(sw, dw, f), kc.resize_upsample_plan(sh, dh, f)
-    expect_new = ph is not None and pv is not None and ph["taps"] == pv["taps"] and ph["ratio"] % 4 == 0
+    expect_new = ph is not None and pv is not None and ph["taps"] == pv["taps"] and (
+        ph["ratio"] % 4 == 0 or (ph["ratio"] == 2 and dw % 4 == 0 and sw >= 8))
     n0 = kc.stats_counter("upsample_launches")
     got = kc.resize_image(kc.SlotImage.from_planes([p]), (dw, dh), f).planes()[0]
     assert (kc.stats_counter("upsample_launches") - n0 == 1) == expect_new
@@ -103,7 +109,8 @@ def _mix(kc, op, left, right):
 
 @pytest.mark.parametrize("specialize", [0, 2])
 @pytest.mark.parametrize("filt", ["Triangle", "Nearest"])
-@pytest.mark.parametrize("small,big", [((16, 16), (128, 128)), ((130, 12), (2080, 96)), ((37, 5), (148, 15)), ((64, 64), (256, 512))])
+@pytest.mark.parametrize("small,big", [((16, 16), (128, 128)), ((130, 12), (2080, 96)), ((37, 5), (148, 15)), ((64, 64), (256, 512)),
+                                       ((64, 40), (128, 80)), ((1100, 16), (2200, 64))])  # the last two: ratio 2 across
 def test_fused_upsample_chain_bit_exact(kc, orc, small, big, filt, specialize):
     """The resampled operand feeds a Mix chain inside one launch (config #2's shape): K = 2 resident + resampled."""
     (sw, sh), (dw, dh) = small, big
