@@ -1713,30 +1713,37 @@ struct UpHardwired {
 #else
 #define KC_UP_ATTR
 #endif
-template <int K, int T, bool WIDE>
+template <int K, int T, bool WIDE, bool HALF>  // HALF: the horizontal ratio is 2 (upsample.h)
 __global__ __launch_bounds__(256) KC_UP_ATTR void upsample_chain_kernel(const ChainProgram P, const UpsampleArgs U)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef KC_UP_HARDWIRE
-    upsample_chain_tile<K, T, KC_UP_RU, WIDE, 0u>(P, U, lds, UpHardwired<K, KC_UP_RU>{});
+    upsample_chain_tile<K, T, KC_UP_RU, WIDE, 0u, HALF>(P, U, lds, UpHardwired<K, KC_UP_RU>{});
 #else
-    upsample_chain_tile<K, T, KC_UP_RU, WIDE, 0u>(P, U, lds, UpInterpreted<K, KC_UP_RU>{ P });
+    upsample_chain_tile<K, T, KC_UP_RU, WIDE, 0u, HALF>(P, U, lds, UpInterpreted<K, KC_UP_RU>{ P });
 #endif
 }
 
-template <int T, bool WIDE, bool NTS>  // NTS: the resampled planes are stored nontemporal (cache_policy_mask)
+template <int T, bool WIDE, bool NTS, bool HALF>  // NTS: the resampled planes are stored nontemporal (cache_policy_mask)
 __global__ __launch_bounds__(256) void upsample_kernel(const UpsamplePlanes P, const UpsampleArgs U)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    upsample_chain_tile<1, T, KC_UP_RU, WIDE, (NTS ? 0x100u : 0u)>(P, U, lds, UpStore<KC_UP_RU>{});
+    upsample_chain_tile<1, T, KC_UP_RU, WIDE, (NTS ? 0x100u : 0u), HALF>(P, U, lds, UpStore<KC_UP_RU>{});
 }
 
 template <int K, bool WIDE>
 static hipError_t launch_upsample_chain_k(const ChainProgram &p, const UpsampleArgs &u, dim3 grid, size_t lds, hipStream_t s)
 {
+    const bool half = u.H.ratio == 2;
     switch (u.H.taps) {
-    case 1: upsample_chain_kernel<K, 1, WIDE><<<grid, 256, lds, s>>>(p, u); break;
-    case 3: upsample_chain_kernel<K, 3, WIDE><<<grid, 256, lds, s>>>(p, u); break;
+    case 1:
+        if (half) upsample_chain_kernel<K, 1, WIDE, true><<<grid, 256, lds, s>>>(p, u);
+        else upsample_chain_kernel<K, 1, WIDE, false><<<grid, 256, lds, s>>>(p, u);
+        break;
+    case 3:
+        if (half) upsample_chain_kernel<K, 3, WIDE, true><<<grid, 256, lds, s>>>(p, u);
+        else upsample_chain_kernel<K, 3, WIDE, false><<<grid, 256, lds, s>>>(p, u);
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1761,13 +1768,19 @@ hipError_t launch_upsample_chain(const ChainProgram &p, int batch, const Upsampl
 template <bool WIDE, bool NTS>
 static hipError_t launch_upsample_w(const UpsamplePlanes &p, const UpsampleArgs &u, dim3 grid, size_t lds, hipStream_t s)
 {
+#define KC_UP_LAUNCH(T)                                                                 \
+    do {                                                                               \
+        if (u.H.ratio == 2) upsample_kernel<T, WIDE, NTS, true><<<grid, 256, lds, s>>>(p, u);  \
+        else upsample_kernel<T, WIDE, NTS, false><<<grid, 256, lds, s>>>(p, u);        \
+    } while (0)
     switch (u.H.taps) {
-    case 1: upsample_kernel<1, WIDE, NTS><<<grid, 256, lds, s>>>(p, u); break;
-    case 3: upsample_kernel<3, WIDE, NTS><<<grid, 256, lds, s>>>(p, u); break;
-    case 5: upsample_kernel<5, WIDE, NTS><<<grid, 256, lds, s>>>(p, u); break;
-    case 7: upsample_kernel<7, WIDE, NTS><<<grid, 256, lds, s>>>(p, u); break;
+    case 1: KC_UP_LAUNCH(1); break;
+    case 3: KC_UP_LAUNCH(3); break;
+    case 5: KC_UP_LAUNCH(5); break;
+    case 7: KC_UP_LAUNCH(7); break;
     default: return hipErrorInvalidValue;
     }
+#undef KC_UP_LAUNCH
     return hipGetLastError();
 }
 

@@ -104,15 +104,19 @@ def test_down2_kernels_fit_their_budgets(usage):
 
 def test_upsample_kernels_fit_their_budgets(usage):
     # the plain integer-ratio up-sampling kernel (Triangle, wide tiles): 8 waves per SIMD
-    for frag in ("upsample_kernelILi3ELb1ELb0EEE", "upsample_kernelILi3ELb1ELb1EEE", "upsample_kernelILi1ELb1ELb0EEE"):
+    # (template arguments: taps, wide tile, nontemporal stores, ratio 2 = half quads)
+    for frag in ("upsample_kernelILi3ELb1ELb0ELb0EEE", "upsample_kernelILi3ELb1ELb1ELb0EEE", "upsample_kernelILi1ELb1ELb0ELb0EEE",
+                 "upsample_kernelILi3ELb1ELb0ELb1EEE", "upsample_kernelILi3ELb1ELb1ELb1EEE"):
         (u,) = find(usage, frag)
         assert u["VGPRs"] <= 64, (frag, u)
-    for frag in ("upsample_kernelILi7ELb1ELb0EEE", "upsample_kernelILi5ELb0ELb0EEE"):
+    for frag in ("upsample_kernelILi7ELb1ELb0ELb0EEE", "upsample_kernelILi5ELb0ELb0ELb0EEE", "upsample_kernelILi7ELb1ELb0ELb1EEE",
+                 "upsample_kernelILi5ELb1ELb1ELb1EEE"):
         (u,) = find(usage, frag)
         assert u["VGPRs"] <= 96, (frag, u)
     # the interpreter-driven fused form (first sightings only): what resize_chain_kernel<2,3> needed 108 for
-    (u,) = find(usage, "upsample_chain_kernelILi2ELi3ELb1EEE")
-    assert u["VGPRs"] <= 96, u
+    for frag in ("upsample_chain_kernelILi2ELi3ELb1ELb0EEE", "upsample_chain_kernelILi2ELi3ELb1ELb1EEE"):
+        (u,) = find(usage, frag)
+        assert u["VGPRs"] <= 96, (frag, u)
     for name, u in usage.items():
         if "chain1_kernel" in name or "upsample" in name:
             assert u.get("ScratchSize", 0) == 0, (name, u)
